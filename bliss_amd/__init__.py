@@ -1,0 +1,15 @@
+"""bliss_amd — MI355X-native implementation of the bliss per-song analysis hot path.
+
+Python surface mirrors the reference's `bliss` package (ref python/bliss/__init__.py:7-12)
+for the analysis path and adds the batch entry points of include/bliss_amd.h.
+All computation happens in libbliss_amd.so (hand-written HIP kernels for gfx950).
+"""
+from . import _lib
+from ._lib import (BL_CALM, BL_LOUD, BL_OK, BL_UNEXPECTED, BL_UNKNOWN, BlSong, EnvelopeResult,
+                   ForceVector, SongDesc, SongResult, load)
+from .batch import (DeviceCorpus, analyze_batch_host, cosine_matrix, distance_matrix,
+                    results_to_numpy)
+
+__all__ = ["_lib", "load", "BlSong", "ForceVector", "EnvelopeResult", "SongDesc", "SongResult",
+           "BL_LOUD", "BL_CALM", "BL_UNKNOWN", "BL_UNEXPECTED", "BL_OK", "DeviceCorpus",
+           "analyze_batch_host", "distance_matrix", "cosine_matrix", "results_to_numpy"]

@@ -1,0 +1,128 @@
+"""Batch helpers over the C-ABI: device-resident corpora (torch owns the memory,
+the library owns the arithmetic) and host-pointer conveniences."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+RESULT_DTYPE = np.dtype([
+    ("tempo", "<f4"), ("amplitude", "<f4"), ("frequency", "<f4"), ("attack", "<f4"),
+    ("force", "<f4"), ("calm_or_loud", "<i4"), ("status", "<i4"), ("start", "<i4"),
+    ("end", "<i4"), ("mean", "<i4"), ("variance", "<i4"), ("n_frames", "<i4"),
+    ("nb_frames", "<i4"), ("n_windows", "<i4"), ("beat", "<i4"), ("hist_integral", "<f4"),
+    ("freq_peak", "<f4"), ("atk_sum", "<f8")], align=True)
+assert RESULT_DTYPE.itemsize == C.sizeof(_lib.SongResult) == 80
+
+
+def results_to_numpy(raw_bytes):
+    """bytes / uint8 array of bl_amd_song_result records -> structured numpy array."""
+    return np.frombuffer(bytes(raw_bytes), dtype=RESULT_DTYPE).copy()
+
+
+def _check(rc, what):
+    if rc != _lib.BL_OK:
+        raise RuntimeError(f"{what} failed with BL_UNEXPECTED ({rc}); see stderr")
+
+
+class DeviceCorpus:
+    """n_songs decoded songs laid out in one int16 arena in HBM.
+
+    lengths: interleaved sample counts; channels / durations: per song (or scalars).
+    The arena is a torch int16 CUDA tensor; every song starts at a multiple of 8 samples.
+    """
+
+    def __init__(self, lengths, channels, durations, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        n = len(lengths)
+        channels = [channels] * n if np.isscalar(channels) else list(channels)
+        durations = [durations] * n if np.isscalar(durations) else list(durations)
+        self.n_songs = n
+        self.desc = (_lib.SongDesc * n)()
+        off = 0
+        for i, (ln, ch, du) in enumerate(zip(lengths, channels, durations)):
+            self.desc[i].pcm_offset = off
+            self.desc[i].n_samples = int(ln)
+            self.desc[i].channels = int(ch)
+            self.desc[i].duration = int(du)
+            off += (int(ln) + 7) & ~7
+        self.total_samples = off
+        idx = self.device.index if self.device.index is not None else 0
+        with torch.cuda.device(idx):
+            _check(self.lib.bl_amd_init(idx), "bl_amd_init")
+            self.pcm = torch.zeros(off + 64, dtype=torch.int16, device=self.device)
+            self.results = torch.zeros(n * C.sizeof(_lib.SongResult), dtype=torch.uint8,
+                                       device=self.device)
+
+    @property
+    def pcm_bytes(self):
+        return 2 * sum(int(d.n_samples) for d in self.desc)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synth(self, seed_base, sample_rate):
+        _check(self.lib.bl_amd_synth_pcm_device(C.c_void_p(self.pcm.data_ptr()), self.desc,
+                                                self.n_songs, seed_base, sample_rate,
+                                                self._stream()), "bl_amd_synth_pcm_device")
+
+    def upload(self, index, pcm_int16):
+        t = self.torch.from_numpy(np.ascontiguousarray(pcm_int16, dtype=np.int16))
+        o = int(self.desc[index].pcm_offset)
+        assert t.numel() == self.desc[index].n_samples
+        self.pcm[o:o + t.numel()].copy_(t)
+
+    def analyze(self):
+        _check(self.lib.bl_amd_analyze_batch_device(C.c_void_p(self.pcm.data_ptr()), self.desc,
+                                                    self.n_songs,
+                                                    C.c_void_p(self.results.data_ptr()),
+                                                    self._stream()), "bl_amd_analyze_batch_device")
+
+    def fetch(self):
+        self.torch.cuda.synchronize(self.device)
+        return results_to_numpy(self.results.cpu().numpy().tobytes())
+
+    def force_vectors(self):
+        """(n_songs, 4) float32 CUDA tensor view-copy of the force vectors."""
+        rec = self.results.view(self.n_songs, C.sizeof(_lib.SongResult))
+        return rec[:, :16].contiguous().view(self.torch.float32).view(self.n_songs, 4)
+
+
+def analyze_batch_host(pcm_list, channels, durations):
+    """pcm_list: list of 1-D int16 numpy arrays (interleaved).  Returns structured results."""
+    lib = _lib.load()
+    n = len(pcm_list)
+    arrs = [np.ascontiguousarray(p, dtype=np.int16) for p in pcm_list]
+    channels = [channels] * n if np.isscalar(channels) else list(channels)
+    durations = [durations] * n if np.isscalar(durations) else list(durations)
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    ns = (C.c_int32 * n)(*[a.size for a in arrs])
+    chs = (C.c_int32 * n)(*channels)
+    dus = (C.c_uint64 * n)(*durations)
+    out = (_lib.SongResult * n)()
+    _check(lib.bl_amd_analyze_batch_host(ptrs, ns, chs, dus, n, out), "bl_amd_analyze_batch_host")
+    return results_to_numpy(bytes(out))
+
+
+def _matrix(fn_name, vecs):
+    lib = _lib.load()
+    v = np.ascontiguousarray(vecs, dtype=np.float32).reshape(-1, 4)
+    n = v.shape[0]
+    out = np.empty((n, n), dtype=np.float32)
+    rc = getattr(lib, fn_name)(v.ctypes.data_as(C.POINTER(_lib.ForceVector)), n,
+                               out.ctypes.data_as(C.POINTER(C.c_float)))
+    _check(rc, fn_name)
+    return out
+
+
+def distance_matrix(vecs):
+    """N x N bl_distance matrix (ref src/analyze.c:96-100) of (N, 4) force vectors."""
+    return _matrix("bl_amd_distance_matrix_host", vecs)
+
+
+def cosine_matrix(vecs):
+    """N x N bl_cosine_similarity matrix (ref src/analyze.c:135-140)."""
+    return _matrix("bl_amd_cosine_matrix_host", vecs)

@@ -1,0 +1,179 @@
+/*
+ * bl_fft.h — 512-point real forward DFT, spread over 16 lanes x 16 registers.
+ *
+ * Replaces the two third-party FFTs the reference calls on the hot path:
+ *   libavcodec av_rdft_calc (f32)  — ref src/frequency_sort.c:83
+ *   FFTW3 fftw_execute r2c (f64)   — ref src/tempo_atk_sort.c:141
+ * Only |X_k|^2 (k = 0..256) is consumed by either caller
+ * (ref src/frequency_sort.c:88-93, src/tempo_atk_sort.c:142-149).
+ *
+ * Mapping (CDNA4 wave64 = 4 independent 16-lane groups, one transform each):
+ *   real x[0..511] is packed as 256 complex z[m] = x[2m] + i x[2m+1];
+ *   m = 16*m1 + n0: lane n0 holds z for m1 = 0..15 in registers.
+ *   pass 1: 16-point DFT over m1 in registers, twiddle W256^(n0*k1),
+ *   one 16x16 transpose through LDS (row stride 17 -> conflict free),
+ *   pass 2: 16-point DFT over n0 -> lane k1 holds Z[k1 + 16*k0];
+ *   real split: lane k1 forms the 8 pairs (k, 256-k), k = k1+16*k0, k0 < 8,
+ *   fetching the partner half-row from lane (16-k1)%16 through LDS.
+ * FMA is used inside the transform (it is our FFT; its rounding is as
+ * implementation-defined as FFTW's), never outside it.
+ *
+ * Everything here is __host__ __device__ so tests can run the exact same
+ * arithmetic lane-by-lane on the CPU (tests/host/test_fft_host.cpp).
+ */
+#ifndef BL_FFT_H_
+#define BL_FFT_H_
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BL_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define BL_HD static inline
+#endif
+
+template <typename T> struct bl_c2 { T re, im; };
+
+BL_HD double bl_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+BL_HD float bl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+/* forward 4-point DFT in place: (a,b,c,d) = x0..x3 -> X0..X3, W4 = -i */
+template <typename T>
+BL_HD void bl_r4(T &ar, T &ai, T &br, T &bi, T &cr, T &ci, T &dr, T &di) {
+  T t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+  T t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
+  ar = t0r + t2r; ai = t0i + t2i;
+  cr = t0r - t2r; ci = t0i - t2i;
+  br = t1r + t3i; bi = t1i - t3r;
+  dr = t1r - t3i; di = t1i + t3r;
+}
+
+/* (r,i) *= (wr + i wi) */
+template <typename T> BL_HD void bl_cmul(T &r, T &i, T wr, T wi) {
+  T p = i * wi, q = i * wr;
+  T nr = bl_fma(r, wr, -p);
+  T ni = bl_fma(r, wi, q);
+  r = nr; i = ni;
+}
+
+/*
+ * Forward 16-point DFT in place.  Input index n = 0..15 natural order.
+ * Output X[k] is left at position bl_pos16(k) = 4*(k%4) + k/4.
+ */
+BL_HD constexpr int bl_pos16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <typename T> BL_HD void bl_fft16(T (&re)[16], T (&im)[16]) {
+  const T C1 = (T)0.92387953251128673848, S1 = (T)0.38268343236508978178;
+  const T R = (T)0.70710678118654752440;
+#pragma unroll
+  for (int n0 = 0; n0 < 4; ++n0)
+    bl_r4(re[n0], im[n0], re[4 + n0], im[4 + n0], re[8 + n0], im[8 + n0], re[12 + n0], im[12 + n0]);
+  /* element 4*k1 + n0 now holds A[n0][k1]; multiply by W16^(n0*k1) */
+  /* exponent 1: (n0,k1) = (1,1) -> idx 5 */
+  bl_cmul(re[5], im[5], C1, -S1);
+  /* exponent 2: (1,2) idx 9, (2,1) idx 6 : *(R - iR) */
+  { T a = re[9], b = im[9]; re[9] = R * (a + b); im[9] = R * (b - a); }
+  { T a = re[6], b = im[6]; re[6] = R * (a + b); im[6] = R * (b - a); }
+  /* exponent 3: (1,3) idx 13, (3,1) idx 7 */
+  bl_cmul(re[13], im[13], S1, -C1);
+  bl_cmul(re[7], im[7], S1, -C1);
+  /* exponent 4: (2,2) idx 10 : * (-i) */
+  { T a = re[10], b = im[10]; re[10] = b; im[10] = -a; }
+  /* exponent 6: (2,3) idx 14, (3,2) idx 11 : *(-R - iR) */
+  { T a = re[14], b = im[14]; re[14] = R * (b - a); im[14] = -(R * (a + b)); }
+  { T a = re[11], b = im[11]; re[11] = R * (b - a); im[11] = -(R * (a + b)); }
+  /* exponent 9: (3,3) idx 15 : * (-C1 + i S1) */
+  bl_cmul(re[15], im[15], -C1, S1);
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1)
+    bl_r4(re[4 * k1], im[4 * k1], re[4 * k1 + 1], im[4 * k1 + 1], re[4 * k1 + 2], im[4 * k1 + 2],
+          re[4 * k1 + 3], im[4 * k1 + 3]);
+  /* element 4*k1 + k0 holds X[k1 + 4*k0] */
+}
+
+/* LDS footprint of one 16-lane transform, in complex elements */
+#define BL_FFT_XCH_ELEMS (16 * 17) /* transpose buffer, row stride 17 */
+#define BL_FFT_PAR_ELEMS (16 * 8)  /* partner half rows */
+
+/*
+ * Phase A (per lane n0): registers hold z[16*m1 + n0], m1 = 0..15.
+ * Does pass 1, applies W256^(n0*k1) and writes row-major [k1][n0] (stride 17).
+ * tw256: table of W256^e = exp(-2 pi i e/256), e = 0..255.
+ */
+template <typename T>
+BL_HD void bl_fft512_phaseA(int n0, T (&re)[16], T (&im)[16], const bl_c2<T> *tw256,
+                            bl_c2<T> *xch) {
+  bl_fft16(re, im);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) {
+    const int p = bl_pos16(k1);
+    T r = re[p], i = im[p];
+    if (k1 != 0) {
+      bl_c2<T> w = tw256[(n0 * k1) & 255];
+      if (n0 != 0) bl_cmul(r, i, w.re, w.im);
+    }
+    bl_c2<T> v; v.re = r; v.im = i;
+    xch[k1 * 17 + n0] = v;
+  }
+}
+
+/*
+ * Phase B (per lane k1, after a barrier): reads column -> pass 2 ->
+ * registers hold Z[k1 + 16*k0] at position bl_pos16(k0); publishes the upper
+ * half row (k0 = 8..15) for the partner lane.
+ */
+template <typename T>
+BL_HD void bl_fft512_phaseB(int k1, T (&re)[16], T (&im)[16], const bl_c2<T> *xch,
+                            bl_c2<T> *par) {
+#pragma unroll
+  for (int n0 = 0; n0 < 16; ++n0) {
+    bl_c2<T> v = xch[k1 * 17 + n0];
+    re[n0] = v.re; im[n0] = v.im;
+  }
+  bl_fft16(re, im);
+#pragma unroll
+  for (int k0 = 8; k0 < 16; ++k0) {
+    bl_c2<T> v; v.re = re[bl_pos16(k0)]; v.im = im[bl_pos16(k0)];
+    par[k1 * 8 + (k0 - 8)] = v;
+  }
+}
+
+/*
+ * Phase C (per lane k1, after a barrier): power of the real-input spectrum.
+ *   own[k0]  = |X_k|^2      , k = k1 + 16*k0      (k0 = 0..7  -> k in 0..127)
+ *   mir[k0]  = |X_(256-k)|^2                       (-> 129..256)
+ *   mid      = |X_128|^2 (meaningful in lane 0 only)
+ * tw512: W512^k = exp(-2 pi i k/512), k = 0..255.
+ */
+template <typename T>
+BL_HD void bl_fft512_phaseC(int k1, const T (&re)[16], const T (&im)[16], const bl_c2<T> *tw512,
+                            const bl_c2<T> *par, T (&own)[8], T (&mir)[8], T &mid) {
+  const int pl = (16 - k1) & 15;
+#pragma unroll
+  for (int k0 = 0; k0 < 8; ++k0) {
+    const T zr = re[bl_pos16(k0)], zi = im[bl_pos16(k0)];
+    T pr, pi;
+    if (k1 != 0) {
+      bl_c2<T> v = par[pl * 8 + (7 - k0)];
+      pr = v.re; pi = v.im;
+    } else if (k0 == 0) {
+      pr = zr; pi = zi;
+    } else {
+      bl_c2<T> v = par[0 * 8 + (8 - k0)];
+      pr = v.re; pi = v.im;
+    }
+    const bl_c2<T> w = tw512[k1 + 16 * k0];
+    const T er = zr + pr, ei = zi - pi;
+    const T orr = zi + pi, oi = pr - zr;
+    const T q = oi * w.im, s = oi * w.re;
+    const T tr = bl_fma(orr, w.re, -q);
+    const T ti = bl_fma(orr, w.im, s);
+    const T ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
+    own[k0] = (T)0.25 * bl_fma(ar, ar, ai * ai);
+    mir[k0] = (T)0.25 * bl_fma(br, br, bi * bi);
+  }
+  const T mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
+  mid = bl_fma(mr, mr, mi * mi);
+}
+
+#endif /* BL_FFT_H_ */

@@ -1,0 +1,1351 @@
+/*
+ * bl_kernels.hip — gfx950 (MI355X, CDNA4) kernels and launch layer of the bliss
+ * per-song analysis path.  Written for wave64 / 160 KiB LDS / 256 CUs; no other
+ * target is supported.  Must be compiled with -ffp-contract=off: everything
+ * outside bl_fft.h follows the reference's unfused x86-64 SSE2 arithmetic
+ * (ref CMakeLists.txt:22, -std=c99) operation by operation.
+ *
+ * Kernels (reference code each one replaces):
+ *   k_pcm_scan     sum, sum of squares, first/last non-zero index, central
+ *                  histogram in one pass        ref src/helpers.c:30-49,
+ *                                               src/amplitude_sort.c:26-39
+ *   k_song_prep    bl_mean / bl_variance values, start/end, reciprocal used by
+ *                  the normalisation            ref src/tempo_atk_sort.c:101-107
+ *   k_variance_wrap  exact int32-wrapping bl_variance for |mean| > 13571
+ *   k_amp_finish   301-pass smoothing + integral ref src/amplitude_sort.c:41-79
+ *   k_freq_frames  Hann + 512-pt f32 real DFT power, summed over frames
+ *                                               ref src/frequency_sort.c:67-94
+ *   k_freq_finish  dB spectrum, 5 bands, score  ref src/frequency_sort.c:97-139
+ *   k_env_windows  normalise, 17-tap FIR, 512-pt f64 real DFT, f32-rounded
+ *                  energy per window            ref src/tempo_atk_sort.c:109-153
+ *   k_env_tail     log-compress, IIR, box filters, peaks, tempo/attack, force
+ *                                               ref src/tempo_atk_sort.c:184-284,
+ *                                               src/analyze.c:63-80
+ *   k_pairwise     bl_distance / bl_cosine_similarity matrix
+ *                                               ref src/analyze.c:96-100,135-140
+ *   k_synth        integer synthetic PCM (benchmark corpus)
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+#include "bl_device.h"
+#include "bl_fft.h"
+#include "bl_tail.h"
+
+#define BL_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      fprintf(stderr, "bliss_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+              __FILE__, __LINE__);                                                      \
+      return BL_UNEXPECTED;                                                             \
+    }                                                                                   \
+  } while (0)
+
+/* ------------------------------------------------------------------------- */
+/* device-side records                                                        */
+
+struct bl_dsong {
+  unsigned long long pcm_off;  /* int16 elements from the arena base */
+  unsigned long long duration; /* seconds */
+  long long env_off;           /* first slot of this song in the per-window arrays */
+  int n, channels;
+  int n_frames;  /* (n / channels) / 512              ref frequency_sort.c:50 */
+  int nb_frames; /* 2 * floor(n / 512)                ref tempo_atk_sort.c:63-64 */
+  int n_windows; /* nb_frames - 2 windows of hop 256  ref tempo_atk_sort.c:66-67,120 */
+  int pad;
+};
+
+struct bl_dstats {
+  unsigned long long sum;   /* two's-complement sum of all samples */
+  unsigned long long sumsq; /* sum of squares */
+  unsigned first;           /* first index with a non-zero sample */
+  int last;                 /* last index with a non-zero sample */
+  int mean, variance;
+  double vprime; /* variance * 2^-15 */
+  double rcp;    /* RN(1 / vprime) */
+  int wrap_pass; /* 1: variance must come from k_variance_wrap */
+  int status;
+  long long wrap_acc; /* accumulator of k_variance_wrap */
+};
+
+typedef bl_c2<double> c2d;
+typedef bl_c2<float> c2f;
+
+/* FIR taps: literal digits of ref include/bandpass_coeffs.h:1-7 (symmetric) */
+#define BL_C0 (-0.0023470)
+#define BL_C1 0.0044613
+#define BL_C2 (-0.0114627)
+#define BL_C3 0.0226382
+#define BL_C4 (-0.0405147)
+#define BL_C5 0.0580037
+#define BL_C6 (-0.0779167)
+#define BL_C7 0.0882711
+#define BL_C8 0.9065095
+
+/* ------------------------------------------------------------------------- */
+/* k_pcm_scan                                                                 */
+
+__device__ __forceinline__ void scan_sample(int s, unsigned idx, long long &sum,
+                                            unsigned long long &sq, unsigned &first, int &last,
+                                            unsigned *lh) {
+  sum += s;
+  sq += (unsigned)(s * s);
+  if (s != 0) {
+    first = min(first, idx);
+    last = max(last, (int)idx);
+  }
+  const unsigned b = (unsigned)(s + BL_HIST_BINS / 2);
+  if (b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pcm,
+                                                  const bl_dsong *__restrict__ songs,
+                                                  bl_dstats *stats, unsigned *hist) {
+  __shared__ unsigned lh[BL_HIST_BINS];
+  const int tid = threadIdx.x;
+  const bl_dsong sg = songs[blockIdx.y];
+  const int16_t *p = pcm + sg.pcm_off;
+  for (int i = tid; i < BL_HIST_BINS; i += 256) lh[i] = 0;
+  __syncthreads();
+
+  long long sum = 0;
+  unsigned long long sq = 0;
+  unsigned first = 0xFFFFFFFFu;
+  int last = -1;
+  const unsigned nvec = (unsigned)sg.n >> 3;
+  const uint4 *pv = reinterpret_cast<const uint4 *>(p);
+  for (unsigned v = blockIdx.x * 256u + tid; v < nvec; v += gridDim.x * 256u) {
+    const uint4 q = pv[v];
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
+      scan_sample(lo, 8u * v + 2u * k, sum, sq, first, last, lh);
+      scan_sample(hi, 8u * v + 2u * k + 1u, sum, sq, first, last, lh);
+    }
+  }
+  if (blockIdx.x == 0 && tid < (sg.n & 7)) {
+    const unsigned idx = 8u * nvec + tid;
+    scan_sample((int)p[idx], idx, sum, sq, first, last, lh);
+  }
+  /* wave reduction, then one set of atomics per wave */
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off);
+    sq += __shfl_down(sq, off);
+    first = min(first, (unsigned)__shfl_down((int)first, off));
+    last = max(last, __shfl_down(last, off));
+  }
+  bl_dstats *st = stats + blockIdx.y;
+  if ((tid & 63) == 0) {
+    atomicAdd(&st->sum, (unsigned long long)sum);
+    atomicAdd(&st->sumsq, sq);
+    atomicMin(&st->first, first);
+    atomicMax(&st->last, last);
+  }
+  __syncthreads();
+  unsigned *gh = hist + (size_t)blockIdx.y * BL_HIST_BINS;
+  for (int i = tid; i < BL_HIST_BINS; i += 256) {
+    const unsigned c = lh[i];
+    if (c) atomicAdd(&gh[i], c);
+  }
+}
+
+__global__ void k_stats_init(bl_dstats *stats, int n_songs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_songs) return;
+  bl_dstats s;
+  s.sum = 0; s.sumsq = 0; s.first = 0xFFFFFFFFu; s.last = -1;
+  s.mean = 0; s.variance = 0; s.vprime = 0; s.rcp = 0; s.wrap_pass = 0; s.status = BL_OK;
+  s.wrap_acc = 0;
+  stats[i] = s;
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_song_prep: one thread per song                                           */
+
+__device__ __forceinline__ void prep_finish(bl_dstats &s, int n) {
+  if (s.variance == 0) s.status = BL_UNEXPECTED; /* reference divides by zero */
+  /* ref tempo_atk_sort.c:105-113: x = (s/2^15 - mean/2^15) / (var/2^30)
+   *   = RN((s - mean) / (var * 2^-15)) exactly (power-of-two scalings commute
+   *   with rounding); vprime and its reciprocal feed bl_norm() below. */
+  s.vprime = (double)s.variance / 32768.0;
+  s.rcp = 1.0 / s.vprime;
+  (void)n;
+}
+
+__global__ void k_song_prep(const bl_dsong *__restrict__ songs, bl_dstats *stats, int n_songs,
+                            bl_amd_song_result *res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_songs) return;
+  bl_dstats s = stats[i];
+  const bl_dsong sg = songs[i];
+  const int n = sg.n;
+  if (s.first == 0xFFFFFFFFu) { /* all-zero PCM: the reference's trim loops never end */
+    s.status = BL_UNEXPECTED;
+    s.first = 0; s.last = n - 1;
+  }
+  /* ref helpers.c:30-37: int32 accumulator (wraps), C truncating division */
+  const int wrapped = (int)(unsigned)(s.sum & 0xFFFFFFFFull);
+  s.mean = wrapped / n;
+  /* ref helpers.c:39-49: sum of (int32)(v*v), v = sample - mean.  Without int32
+   * overflow of v*v (|v| <= 46340, guaranteed when |mean| <= 13571) this is
+   * sumsq - 2*mean*sum + n*mean^2 in exact integer arithmetic. */
+  const long long m = s.mean;
+  if (m > 13571 || m < -13571) {
+    s.wrap_pass = 1;
+  } else {
+    const long long acc = (long long)s.sumsq - 2 * m * (long long)s.sum + (long long)n * m * m;
+    s.variance = (int)(acc / n);
+    prep_finish(s, n);
+  }
+  stats[i] = s;
+  bl_amd_song_result *r = res + i;
+  r->start = (int)s.first; r->end = s.last;
+  r->mean = s.mean; r->variance = s.variance;
+  r->n_frames = sg.n_frames; r->nb_frames = sg.nb_frames; r->n_windows = sg.n_windows;
+  r->status = s.status;
+}
+
+/* exact restatement of ref helpers.c:39-49 including the int32 wrap of v*v;
+ * only songs flagged by k_song_prep do any work */
+__global__ __launch_bounds__(256) void k_variance_wrap(const int16_t *__restrict__ pcm,
+                                                       const bl_dsong *__restrict__ songs,
+                                                       bl_dstats *stats) {
+  bl_dstats *st = stats + blockIdx.y;
+  if (!st->wrap_pass) return;
+  const bl_dsong sg = songs[blockIdx.y];
+  const int16_t *p = pcm + sg.pcm_off;
+  const int mean = st->mean;
+  long long acc = 0;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)sg.n; i += gridDim.x * 256u) {
+    const int v = (int)p[i] - mean;
+    acc += (int)((unsigned)v * (unsigned)v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0)
+    atomicAdd(reinterpret_cast<unsigned long long *>(&st->wrap_acc), (unsigned long long)acc);
+}
+
+__global__ void k_variance_wrap_finish(const bl_dsong *__restrict__ songs, bl_dstats *stats,
+                                       int n_songs, bl_amd_song_result *res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_songs) return;
+  bl_dstats s = stats[i];
+  if (!s.wrap_pass) return;
+  s.variance = (int)(s.wrap_acc / songs[i].n);
+  prep_finish(s, songs[i].n);
+  stats[i] = s;
+  res[i].variance = s.variance;
+  res[i].status = s.status;
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_amp_finish: one block per song                                           */
+
+#define BL_AMP_PASSES 301                         /* g = 0..300, ref amplitude_sort.c:41 */
+#define BL_INT_LO ((32767 - 1000) - BL_HIST_LO)   /* local index of INTEGRAL_INF */
+#define BL_INT_HI ((32767 + 1000) - BL_HIST_LO)   /* local index of INTEGRAL_SUP */
+
+__global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__ songs,
+                                                    const bl_dstats *__restrict__ stats,
+                                                    const unsigned *__restrict__ hist,
+                                                    bl_amd_song_result *res) {
+  __shared__ float buf[2][BL_HIST_BINS + 8];
+  const int tid = threadIdx.x;
+  const int song = blockIdx.x;
+  const bl_dstats st = stats[song];
+  const int n = songs[song].n;
+  const unsigned *gh = hist + (size_t)song * BL_HIST_BINS;
+  const int start = (int)st.first, end = st.last;
+  if (tid < 8) { /* 3 zero cells left of bin 0, 5 right of the last bin */
+    const int c = tid < 3 ? tid : BL_HIST_BINS + tid;
+    buf[0][c] = 0.f; buf[1][c] = 0.f;
+  }
+  for (int i = tid; i < BL_HIST_BINS; i += 256) {
+    unsigned c = gh[i];
+    /* samples outside [start, end] are zeros and are not counted (ref :26-39) */
+    if (i == BL_HIST_BINS / 2) c -= (unsigned)start + (unsigned)(n - 1 - end);
+    /* float += 1 stops growing at 2^24 */
+    buf[0][i + 3] = (float)min(c, 16777216u);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int g = 0; g < BL_AMP_PASSES; ++g) {
+    const float *h = buf[cur] + 3;
+    float *s = buf[cur ^ 1] + 3;
+    for (int i = tid; i < BL_HIST_BINS; i += 256) {
+      /* ref :49-55: f32 sum left to right, times (double)(1/27), stored as f32 */
+      float acc = h[i - 3] + (3 * h[i - 2]);
+      acc = acc + (6 * h[i - 1]);
+      acc = acc + (7 * h[i]);
+      acc = acc + (6 * h[i + 1]);
+      acc = acc + (3 * h[i + 2]);
+      acc = acc + h[i + 3];
+      s[i] = (float)(1. / 27. * (double)acc);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  /* ref :62-66 then :69-71 */
+  float *s = buf[cur] + 3;
+  float *v = buf[cur ^ 1] + 3;
+  const float denom = (float)(start - end);
+  for (int i = BL_INT_LO + tid; i <= BL_INT_HI; i += 256) {
+    float t = s[i] / denom;
+    t = (float)((double)t * 100.);
+    v[i] = fabsf(t);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float integral = 0;
+    for (int i = BL_INT_LO; i <= BL_INT_HI; ++i) integral += v[i];
+    bl_amd_song_result *r = res + song;
+    r->hist_integral = integral;
+    r->v.amplitude = -0.2f * integral + 6.0f; /* ref :79 */
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_freq_frames                                                              */
+
+struct bl_tables {
+  const c2d *tw256_d, *tw512_d;
+  const c2f *tw256_f, *tw512_f;
+  const float *hann;
+  double log101;
+};
+
+#define BL_FREQ_LDS_BYTES                                                              \
+  (16 * BL_FFT_XCH_ELEMS * 8 + 16 * BL_FFT_PAR_ELEMS * 8 + 2 * 256 * 8 + 512 * 4)
+
+__global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__ pcm,
+                                                     const bl_dsong *__restrict__ songs,
+                                                     bl_tables tb, float *partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  c2f *xch = reinterpret_cast<c2f *>(smem);                       /* 16 x 272 */
+  c2f *par = xch + 16 * BL_FFT_XCH_ELEMS;                         /* 16 x 128 */
+  c2f *tw256 = par + 16 * BL_FFT_PAR_ELEMS;
+  c2f *tw512 = tw256 + 256;
+  float *hann = reinterpret_cast<float *>(tw512 + 256);
+  const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
+  const bl_dsong sg = songs[blockIdx.y];
+  const int16_t *p = pcm + sg.pcm_off;
+  tw256[tid] = tb.tw256_f[tid];
+  tw512[tid] = tb.tw512_f[tid];
+  hann[tid] = tb.hann[tid];
+  hann[tid + 256] = tb.hann[tid + 256];
+  __syncthreads();
+
+  float a_own[8], a_mir[8], a_mid = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a_own[k] = 0.f; a_mir[k] = 0.f; }
+  c2f *gx = xch + g * BL_FFT_XCH_ELEMS, *gp = par + g * BL_FFT_PAR_ELEMS;
+
+  for (int base = blockIdx.x * 16; base < sg.n_frames; base += gridDim.x * 16) {
+    const int f = base + g;
+    const bool active = f < sg.n_frames;
+    float re[16], im[16];
+    if (active && sg.channels == 2) {
+      /* ref :69-75: (float)((L + R) / 2) * hann[d], integer average truncates */
+      const uint2 *q = reinterpret_cast<const uint2 *>(p + (size_t)f * 1024);
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) {
+        const uint2 w = q[16 * m1 + l];
+        const int d = 32 * m1 + 2 * l;
+        const int s0 = ((int)(short)(w.x & 0xFFFFu) + (int)(short)(w.x >> 16)) / 2;
+        const int s1 = ((int)(short)(w.y & 0xFFFFu) + (int)(short)(w.y >> 16)) / 2;
+        re[m1] = (float)s0 * hann[d];
+        im[m1] = (float)s1 * hann[d + 1];
+      }
+    } else if (active) { /* ref :76-80 */
+      const unsigned *q = reinterpret_cast<const unsigned *>(p + (size_t)f * 512);
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) {
+        const unsigned w = q[16 * m1 + l];
+        const int d = 32 * m1 + 2 * l;
+        re[m1] = (float)(int)(short)(w & 0xFFFFu) * hann[d];
+        im[m1] = (float)(int)(short)(w >> 16) * hann[d + 1];
+      }
+    } else {
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) { re[m1] = 0.f; im[m1] = 0.f; }
+    }
+    bl_fft512_phaseA<float>(l, re, im, tw256, gx);
+    __syncthreads();
+    bl_fft512_phaseB<float>(l, re, im, gx, gp);
+    __syncthreads();
+    float own[8], mir[8], mid;
+    bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
+    if (active) { /* ref :88-93: power_spectrum[d] += re*re + im*im */
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a_own[k] += own[k]; a_mir[k] += mir[k]; }
+      a_mid += mid;
+    }
+    __syncthreads();
+  }
+  /* fold the 16 groups of the block in a fixed order */
+  float *red = reinterpret_cast<float *>(smem); /* [16][256], aliases xch */
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red[g * 256 + l + 16 * k] = a_own[k];
+    if (l + 16 * k != 0) red[g * 256 + 256 - l - 16 * k] = a_mir[k];
+  }
+  if (l == 0) red[g * 256 + 128] = a_mid;
+  __syncthreads();
+  float acc = 0.f;
+#pragma unroll
+  for (int gg = 0; gg < 16; ++gg) acc += red[gg * 256 + tid];
+  partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ partial, int parts,
+                                                     bl_amd_song_result *res) {
+  __shared__ float ps[256];
+  __shared__ float wmax[4];
+  const int d = threadIdx.x, song = blockIdx.x;
+  float acc = 0.f;
+  const float *pp = partial + (size_t)song * parts * 256 + d;
+  for (int k = 0; k < parts; ++k) acc += pp[(size_t)k * 256];
+  /* ref :97-102: sqrt(ps / 512), peak over d = 1..256 (ps[256] is 0) */
+  float v = d == 0 ? 0.f : (float)sqrt((double)(acc / 512));
+  float m = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+  if ((d & 63) == 0) wmax[d >> 6] = m;
+  __syncthreads();
+  const float peak = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  /* ref :105-107 */
+  ps[d] = (float)(20 * log10((double)(v / peak)) - 3);
+  __syncthreads();
+  if (d == 0) { /* ref :110-139, f32 sequential sums, divisors 50 / 57 / 115 */
+    float b0 = (ps[2] + ps[4]) / 2;
+    float b1 = (ps[6] + ps[8]) / 2;
+    float b2 = 0, b3 = 0, b4 = 0;
+    for (int i = 10; i <= 60; ++i) b2 += ps[i];
+    b2 /= 50;
+    for (int i = 61; i <= 118; ++i) b3 += ps[i];
+    b3 /= 57;
+    for (int i = 119; i <= 234; ++i) b4 += ps[i];
+    b4 /= 115;
+    const float sum = b4 + b3 + b2 - b0 - b1;
+    res[song].freq_peak = peak;
+    res[song].v.frequency = (float)((1. / 3.) * (double)sum + 68. / 3.);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_env_windows                                                              */
+
+#define BL_TILE_W 16                      /* windows per tile (one per 16-lane group) */
+#define BL_TILE_X (BL_TILE_W * 256 + 256) /* 4352 samples feed one tile */
+#define BL_ENV_R1_BYTES (2 * BL_TILE_X * 8) /* x + z, later xch, later par + terms */
+#define BL_ENV_LDS_BYTES (BL_ENV_R1_BYTES + 16 * 8 + BL_TILE_W * 16 * 8 + 2 * 256 * 16)
+
+/* ref tempo_atk_sort.c:109-114 for one sample: RN(((s/2^15) - (mean/2^15)) / vd).
+ * k = s - mean is exact, q0 = k*rcp is within 2 ulp of k/vprime, the remainder
+ * fma is exact and one correction lands on the correctly rounded quotient
+ * (the distance of k/V from a rounding boundary is >= 2^-84 relative for
+ * |k| < 2^17, V < 2^31, far above the 2^-105 error of the corrected value). */
+__device__ __forceinline__ double bl_norm(int k, double vprime, double rcp) {
+  const double kd = (double)k;
+  const double q0 = kd * rcp;
+  const double r0 = __builtin_fma(-q0, vprime, kd);
+  return __builtin_fma(r0, rcp, q0);
+}
+
+#define BL_FIR(X)                                                   \
+  ({                                                                \
+    double y_ = 0;                                                  \
+    y_ += BL_C7 * (X(7) + X(9));                                    \
+    y_ += BL_C6 * (X(6) + X(10));                                   \
+    y_ += BL_C5 * (X(5) + X(11));                                   \
+    y_ += BL_C4 * (X(4) + X(12));                                   \
+    y_ += BL_C3 * (X(3) + X(13));                                   \
+    y_ += BL_C2 * (X(2) + X(14));                                   \
+    y_ += BL_C1 * (X(1) + X(15));                                   \
+    y_ += X(8) * BL_C8;                                             \
+    y_ += BL_C0 * (X(0) + X(16));                                   \
+    y_;                                                             \
+  })
+
+__global__ __launch_bounds__(256) void k_env_windows(const int16_t *__restrict__ pcm,
+                                                     const bl_dsong *__restrict__ songs,
+                                                     const bl_dstats *__restrict__ stats,
+                                                     bl_tables tb, float *energies, double *lc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  /* region R1, three lives per tile */
+  double *xs = reinterpret_cast<double *>(smem);          /* [16 + 4352] normalised x  */
+  double *zs = xs + 16 + BL_TILE_X;                        /* [4352 - 16] FIR output z  */
+  c2d *xch = reinterpret_cast<c2d *>(smem);                /* 16 x 272                  */
+  c2d *par = reinterpret_cast<c2d *>(smem);                /* 16 x 128                  */
+  double *terms = reinterpret_cast<double *>(smem + 16 * BL_FFT_PAR_ELEMS * 16); /* [16][257] */
+  /* persistent */
+  double *heads = reinterpret_cast<double *>(smem + BL_ENV_R1_BYTES + 16 * 8); /* [16][16] */
+  c2d *tw256 = reinterpret_cast<c2d *>(heads + BL_TILE_W * 16);
+  c2d *tw512 = tw256 + 256;
+
+  const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
+  const bl_dsong sg = songs[blockIdx.y];
+  const bl_dstats st = stats[blockIdx.y];
+  const int16_t *p = pcm + sg.pcm_off;
+  const int mean = st.mean;
+  const double vprime = st.vprime, rcp = st.rcp;
+  tw256[tid] = tb.tw256_d[tid];
+  tw512[tid] = tb.tw512_d[tid];
+  if (tid < 16) xs[tid] = 0.0; /* never-used left margin of the FIR registers */
+  const int n_tiles = (sg.n_windows + BL_TILE_W - 1) / BL_TILE_W;
+  const int n_used = 256 * (sg.n_windows + 1); /* samples any window reads */
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int w0 = tile * BL_TILE_W;
+    const int s0 = w0 * 256; /* first sample of the tile */
+    __syncthreads();         /* previous tile's LDS reads are done */
+    /* 1. PCM -> normalised f64 in LDS (8 samples = 16 bytes per load) */
+    for (int c = tid; c < BL_TILE_X / 8; c += 256) {
+      const int i0 = s0 + 8 * c;
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (i0 + 8 <= n_used) q = *reinterpret_cast<const uint4 *>(p + i0);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
+        xs[16 + 8 * c + 2 * k] = bl_norm(lo - mean, vprime, rcp);
+        xs[16 + 8 * c + 2 * k + 1] = bl_norm(hi - mean, vprime, rcp);
+      }
+    }
+    __syncthreads();
+    /* 2a. steady-state FIR: z[j] for the 17 tile-local outputs 17*tid .. 17*tid+16
+     *     (ref :123-138 with a full delay line; identical to the per-window
+     *     zero-state filter for every output >= 16 samples into its window) */
+    {
+      double r[33];
+      const double *xb = xs + 17 * tid; /* xs[16 + jl - 16 + i] */
+#pragma unroll
+      for (int i = 0; i < 33; ++i) r[i] = xb[i];
+#pragma unroll
+      for (int i = 0; i < 17; ++i) {
+#define XR(m) r[i + 16 - (m)]
+        const double y = BL_FIR(XR);
+#undef XR
+        const int jl = 17 * tid + i;
+        if (jl >= 16) zs[jl - 16] = y;
+      }
+    }
+    /* 2b. first 16 outputs of each window: delay line starts from zero (ref :121) */
+    {
+      const double *xw = xs + 16 + 256 * g; /* window g of the tile */
+#define XH(m) ((l - (m)) >= 0 ? xw[l - (m)] : 0.0)
+      heads[g * 16 + l] = BL_FIR(XH);
+#undef XH
+    }
+    __syncthreads();
+    /* 3. FFT input: lane l of group g holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
+    double re[16], im[16];
+    {
+      const double *zw = zs + 256 * g - 16; /* zw[n] = z of window sample n (n >= 16) */
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) {
+        const int nn = 32 * m1 + 2 * l;
+        if (m1 == 0 && l < 8) {
+          re[m1] = heads[g * 16 + nn];
+          im[m1] = heads[g * 16 + nn + 1];
+        } else {
+          re[m1] = zw[nn];
+          im[m1] = zw[nn + 1];
+        }
+      }
+    }
+    __syncthreads(); /* x / z dead, region becomes the transpose buffer */
+    c2d *gx = xch + g * BL_FFT_XCH_ELEMS;
+    bl_fft512_phaseA<double>(l, re, im, tw256, gx);
+    __syncthreads();
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) {
+      const c2d v = gx[l * 17 + n0];
+      re[n0] = v.re; im[n0] = v.im;
+    }
+    __syncthreads(); /* transpose buffer dead, region becomes par + terms */
+    bl_fft16(re, im);
+    c2d *gp = par + g * BL_FFT_PAR_ELEMS;
+#pragma unroll
+    for (int k0 = 8; k0 < 16; ++k0) {
+      c2d v; v.re = re[bl_pos16(k0)]; v.im = im[bl_pos16(k0)];
+      gp[l * 8 + (k0 - 8)] = v;
+    }
+    __syncthreads();
+    {
+      double own[8], mir[8], mid;
+      bl_fft512_phaseC<double>(l, re, im, tw512, gp, own, mir, mid);
+      double *tg = terms + g * 257;
+#pragma unroll
+      for (int k0 = 0; k0 < 8; ++k0) {
+        tg[l + 16 * k0] = own[k0];
+        tg[256 - l - 16 * k0] = mir[k0];
+      }
+      if (l == 0) tg[128] = mid;
+    }
+    __syncthreads();
+    /* 4. ref :142-151: float sum_fft += (double)|X_k|^2, k = 0..256 in order,
+     *    rounded to f32 after every add */
+    if (tid < BL_TILE_W && w0 + tid < sg.n_windows) {
+      const double *tg = terms + tid * 257;
+      float sum = 0.f;
+      for (int k = 0; k <= 256; ++k) sum = (float)((double)sum + tg[k]);
+      energies[sg.env_off + w0 + tid] = sum;
+      lc[sg.env_off + w0 + tid] = bl_tail_compress((double)sum, tb.log101);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_env_tail: one lane per song, 64 songs per wave                           */
+
+__global__ __launch_bounds__(64) void k_env_tail(const bl_dsong *__restrict__ songs,
+                                                 const double *__restrict__ lc, int n_songs,
+                                                 bl_amd_song_result *res, int what) {
+  __shared__ double tile[64 * 65];
+  __shared__ double rings[48 * 64];
+  const int lane = threadIdx.x;
+  const int song = blockIdx.x * 64 + lane;
+  const bool valid = song < n_songs;
+  bl_dsong sg;
+  if (valid) sg = songs[song];
+  else { sg.nb_frames = 0; sg.n_windows = 0; sg.env_off = 0; sg.n = 1; sg.duration = 1; }
+  const int N = 2 * sg.nb_frames;
+  int maxN = N;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
+  bl_tail t;
+  t.init(sg.nb_frames, rings + lane, 64);
+
+  for (int j0 = 0; j0 < maxN; j0 += 128) {
+    /* stage 64 windows x 64 songs of the compressed envelope, transposed */
+    const int wbase = j0 >> 1;
+    for (int s = 0; s < 64; ++s) {
+      const int nw = __shfl(sg.n_windows, s);
+      const long long off = __shfl(sg.env_off, s);
+      const int w = wbase + lane;
+      tile[s * 65 + lane] = (w < nw) ? lc[off + w] : 0.0;
+    }
+    __syncthreads();
+    const int jend = min(128, maxN - j0);
+    for (int jj = 0; jj < jend; ++jj) {
+      const int j = j0 + jj;
+      if (j < N) {
+        const double x = (jj & 1) ? 0.0 : tile[lane * 65 + (jj >> 1)];
+        t.step(j, x);
+        if (j == N - 1) t.finish();
+      }
+    }
+    __syncthreads();
+  }
+  if (!valid) return;
+  bl_amd_song_result *r = res + song;
+  r->beat = t.beat();
+  r->atk_sum = t.atk;
+  r->v.tempo = bl_tail_tempo(t.beat(), sg.duration);
+  r->v.attack = bl_tail_attack(t.atk, sg.n);
+  if (what == 7) {
+    /* ref analyze.c:68-79 */
+    const float rating = (float)(fmax((double)r->v.tempo, 0.0) + (double)r->v.amplitude +
+                                 (double)r->v.frequency + fmax((double)r->v.attack, 0.0));
+    r->force = rating;
+    r->calm_or_loud = rating > 0 ? BL_LOUD : (rating < 0 ? BL_CALM : BL_UNKNOWN);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_pairwise                                                                 */
+
+__device__ __forceinline__ float bl_dist(const float4 a, const float4 b) {
+  /* ref analyze.c:96-100: f32 throughout, left-to-right, sqrt correctly rounded */
+  const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+  const float s = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  return __fsqrt_rn(s);
+}
+
+__device__ __forceinline__ float bl_cos(const float4 a, const float4 b) {
+  /* ref analyze.c:135-140: f32 dot / norms, double sqrt, product and divide */
+  const float dot = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  const float na = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+  const float nb = b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+  return (float)((double)dot / (sqrt((double)na) * sqrt((double)nb)));
+}
+
+template <bool COSINE>
+__global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vecs, int n,
+                                                  int row_begin, float *__restrict__ out) {
+  const int row = blockIdx.y;
+  const float4 a = vecs[row_begin + row];
+  float *orow = out + (size_t)row * n;
+  const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j0 >= n) return;
+  float r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = min(j0 + k, n - 1);
+    const float4 b = vecs[j];
+    r[k] = COSINE ? bl_cos(a, b) : bl_dist(a, b);
+  }
+  if (j0 + 4 <= n && ((reinterpret_cast<size_t>(orow + j0) & 15) == 0)) {
+    *reinterpret_cast<float4 *>(orow + j0) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    for (int k = 0; k < 4 && j0 + k < n; ++k) orow[j0 + k] = r[k];
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_synth: integer-only synthetic PCM, same bytes as oracle/orc_synth.c       */
+
+__device__ __forceinline__ unsigned syn_mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ int syn_psin(unsigned ph) {
+  const int x = (int)(ph & 65535u) - 32768;
+  const int ax = x < 0 ? -x : x;
+  return -((x * (32768 - ax)) / 8192);
+}
+__device__ __forceinline__ short syn_sample(unsigned seed, unsigned rate, unsigned channels,
+                                            unsigned i) {
+  const unsigned f = i / channels, c = i - f * channels;
+  const unsigned h = syn_mix32(seed * 0x9E3779B9u + 1u);
+  const unsigned f1 = 110u + (h & 255u);
+  const unsigned f2 = 2000u + ((h >> 8) & 2047u);
+  const unsigned bpm = 90u + ((h >> 20) & 63u);
+  const unsigned a1 = 3000u + ((h >> 26) & 31u) * 100u;
+  const unsigned period = rate * 60u / bpm;
+  const unsigned pos = f % period;
+  const int env = 32768 - (int)(((unsigned long long)pos * 29491u) / period);
+  const unsigned ph1 = (unsigned)((((unsigned long long)f * f1) << 16) / rate);
+  const unsigned ph2 = (unsigned)((((unsigned long long)f * f2) << 16) / rate) + c * 16384u;
+  const int tone = (syn_psin(ph1) * (int)a1 + syn_psin(ph2) * 2500) / 32768;
+  const int sig = (tone * env) / 32768;
+  const int noise = (int)(syn_mix32(seed ^ syn_mix32(i + 0x1234567u)) % 1601u) - 800;
+  return (short)(sig + noise);
+}
+
+__global__ __launch_bounds__(256) void k_synth(int16_t *pcm, const bl_dsong *__restrict__ songs,
+                                               unsigned seed_base, unsigned rate) {
+  const bl_dsong sg = songs[blockIdx.y];
+  int16_t *p = pcm + sg.pcm_off;
+  const unsigned seed = seed_base + blockIdx.y;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)sg.n; i += gridDim.x * 256u)
+    p[i] = syn_sample(seed, rate, (unsigned)sg.channels, i);
+}
+
+/* single-thread sequential kernels behind the helper shims */
+__global__ void k_rect_filter(double *out, const double *in, int n, int width) {
+  /* ref tempo_atk_sort.c:19-40, literally */
+  const int half = (int)round(width / 2.);
+  double run = 0;
+  for (int k = 0; k < width; ++k) run += in[k];
+  for (int k = 0; k < n - width; ++k) {
+    out[k + half - 1] = run;
+    run -= in[k];
+    run += in[k + width];
+  }
+  for (int k = n - width; k < n; ++k) out[n - half] += in[k];
+  for (int k = 0; k < n; ++k) out[k] /= width;
+}
+
+__global__ void k_pair(const float4 a, const float4 b, int cosine, float *out) {
+  *out = cosine ? bl_cos(a, b) : bl_dist(a, b);
+}
+
+/* ========================================================================= */
+/* host side: context, workspace, launches                                    */
+
+namespace {
+
+enum { PK_SCAN, PK_AMP, PK_FREQ, PK_FREQ_FIN, PK_ENV, PK_TAIL, PK_DIST, PK_COUNT };
+const char *const kProfNames[PK_COUNT] = {"pcm_scan",    "amp_finish", "freq_frames", "freq_finish",
+                                          "env_windows", "env_tail",   "distance"};
+
+struct Buf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct Ctx {
+  std::mutex mu;
+  bool ready = false;
+  int device = 0;
+  int n_cu = 256;
+  bl_tables tb{};
+  void *tables_mem = nullptr;
+  Buf songs, stats, hist, partial, energies, lc, results, misc;
+  /* profiling */
+  bool prof = false;
+  struct Ev { int k; hipEvent_t a, b; };
+  std::vector<Ev> events;
+  double prof_ms[PK_COUNT] = {0};
+  int prof_n[PK_COUNT] = {0};
+  /* host batch staging */
+  void *pinned[2] = {nullptr, nullptr};
+  size_t pinned_cap[2] = {0, 0};
+  Buf arena[2];
+  hipStream_t streams[2] = {nullptr, nullptr};
+};
+
+Ctx g;
+
+int ensure(Buf &b, size_t bytes) {
+  if (bytes <= b.cap) return BL_OK;
+  if (b.p) {
+    BL_HIP_CHECK(hipDeviceSynchronize());
+    BL_HIP_CHECK(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+  }
+  size_t cap = bytes + bytes / 8 + 4096;
+  BL_HIP_CHECK(hipMalloc(&b.p, cap));
+  b.cap = cap;
+  return BL_OK;
+}
+
+int init_locked(int device) {
+  if (g.ready && g.device == device) return BL_OK;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    fprintf(stderr, "bliss_amd: no HIP device available (%s); this library has no CPU path\n",
+            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return BL_UNEXPECTED;
+  }
+  if (device < 0 || device >= count) {
+    fprintf(stderr, "bliss_amd: device %d out of range (%d visible)\n", device, count);
+    return BL_UNEXPECTED;
+  }
+  BL_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  BL_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  /* twiddle / window tables, computed once in double on the host */
+  const double pi = 3.14159265358979323846;
+  std::vector<unsigned char> h(256 * 16 * 2 + 256 * 8 * 2 + 512 * 4);
+  c2d *t256 = reinterpret_cast<c2d *>(h.data());
+  c2d *t512 = t256 + 256;
+  c2f *f256 = reinterpret_cast<c2f *>(t512 + 256);
+  c2f *f512 = f256 + 256;
+  float *hann = reinterpret_cast<float *>(f512 + 256);
+  for (int k = 0; k < 256; ++k) {
+    t256[k].re = cos(2 * pi * k / 256); t256[k].im = -sin(2 * pi * k / 256);
+    t512[k].re = cos(2 * pi * k / 512); t512[k].im = -sin(2 * pi * k / 512);
+    f256[k].re = (float)t256[k].re; f256[k].im = (float)t256[k].im;
+    f512[k].re = (float)t512[k].re; f512[k].im = (float)t512[k].im;
+  }
+  /* ref frequency_sort.c:40-42 */
+  for (int i = 0; i < 512; ++i) hann[i] = (float)(.5f * (1.0f - cos(2 * M_PI * i / (512 - 1))));
+  if (g.tables_mem) { (void)hipFree(g.tables_mem); g.tables_mem = nullptr; }
+  BL_HIP_CHECK(hipMalloc(&g.tables_mem, h.size()));
+  BL_HIP_CHECK(hipMemcpy(g.tables_mem, h.data(), h.size(), hipMemcpyHostToDevice));
+  unsigned char *d = static_cast<unsigned char *>(g.tables_mem);
+  g.tb.tw256_d = reinterpret_cast<const c2d *>(d);
+  g.tb.tw512_d = g.tb.tw256_d + 256;
+  g.tb.tw256_f = reinterpret_cast<const c2f *>(g.tb.tw512_d + 256);
+  g.tb.tw512_f = g.tb.tw256_f + 256;
+  g.tb.hann = reinterpret_cast<const float *>(g.tb.tw512_f + 256);
+  g.tb.log101 = log((double)(1 + 100.0f)); /* ref tempo_atk_sort.c:188, log(1 + mu) */
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_ENV_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
+  g.device = device;
+  g.ready = true;
+  return BL_OK;
+}
+
+struct ProfScope {
+  int k;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(int kk, hipStream_t ss) : k(kk), s(ss) {
+    if (!g.prof) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, s);
+    g.events.push_back({k, a, b});
+  }
+};
+
+void prof_collect() {
+  for (auto &e : g.events) {
+    float ms = 0;
+    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      g.prof_ms[e.k] += ms;
+      g.prof_n[e.k] += 1;
+    }
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  g.events.clear();
+}
+
+/* host mirror of the per-song geometry (integer work of ref tempo_atk_sort.c:63-67,
+ * frequency_sort.c:50) */
+int fill_songs(const bl_amd_song_desc *desc, int n_songs, std::vector<bl_dsong> &out,
+               long long &env_total, int &max_n) {
+  out.resize(n_songs);
+  env_total = 0;
+  max_n = 0;
+  for (int i = 0; i < n_songs; ++i) {
+    const bl_amd_song_desc &d = desc[i];
+    if (d.n_samples < 5120 || (d.channels != 1 && d.channels != 2) || d.duration == 0 ||
+        (d.pcm_offset & 7)) {
+      fprintf(stderr,
+              "bliss_amd: song %d rejected (n_samples=%d channels=%d duration=%llu offset=%llu): "
+              "need n_samples >= 5120, channels 1|2, duration > 0, offset %% 8 == 0\n",
+              i, d.n_samples, d.channels, (unsigned long long)d.duration,
+              (unsigned long long)d.pcm_offset);
+      return BL_UNEXPECTED;
+    }
+    bl_dsong &s = out[i];
+    s.pcm_off = d.pcm_offset;
+    s.duration = d.duration;
+    s.n = d.n_samples;
+    s.channels = d.channels;
+    s.n_frames = (d.n_samples / d.channels) / 512;
+    s.nb_frames = (d.n_samples - (d.n_samples % 512)) * 2 / 512;
+    s.n_windows = s.nb_frames - 2;
+    s.env_off = env_total;
+    s.pad = 0;
+    env_total += s.nb_frames;
+    if (d.n_samples > max_n) max_n = d.n_samples;
+  }
+  return BL_OK;
+}
+
+int grid_x_for(long long units_max, int n_songs, int blocks_per_cu) {
+  /* enough blocks to fill the chip several times over, never more than the
+   * longest song has work for */
+  long long want = ((long long)g.n_cu * blocks_per_cu + n_songs - 1) / n_songs;
+  if (want < 1) want = 1;
+  if (want > units_max) want = units_max;
+  if (want < 1) want = 1;
+  if (want > 65535) want = 65535;
+  return (int)want;
+}
+
+/* analysis of songs [0, n) of one launch group (n <= 32768) */
+int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
+                  bl_amd_song_result *d_results, hipStream_t stream, int what) {
+  std::vector<bl_dsong> hs;
+  long long env_total = 0;
+  int max_n = 0;
+  if (fill_songs(h_desc, n_songs, hs, env_total, max_n) != BL_OK) return BL_UNEXPECTED;
+
+  const int max_frames = (max_n / 512);
+  const int gx_scan = grid_x_for(((long long)max_n / 8 + 255) / 256, n_songs, 8);
+  const int gx_freq = grid_x_for((max_frames + 15) / 16 + 1, n_songs, 6);
+  const int gx_env = grid_x_for((2 * max_frames + BL_TILE_W - 1) / BL_TILE_W, n_songs, 6);
+
+  if (ensure(g.songs, sizeof(bl_dsong) * n_songs) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.stats, sizeof(bl_dstats) * n_songs) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.hist, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.partial, sizeof(float) * 256 * (size_t)gx_freq * n_songs) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.energies, sizeof(float) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.lc, sizeof(double) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
+
+  bl_dsong *d_songs = static_cast<bl_dsong *>(g.songs.p);
+  bl_dstats *d_stats = static_cast<bl_dstats *>(g.stats.p);
+  unsigned *d_hist = static_cast<unsigned *>(g.hist.p);
+  float *d_partial = static_cast<float *>(g.partial.p);
+  float *d_energies = static_cast<float *>(g.energies.p);
+  double *d_lc = static_cast<double *>(g.lc.p);
+
+  BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs.data(), sizeof(bl_dsong) * n_songs, hipMemcpyHostToDevice,
+                              stream));
+  /* the pageable source must stay alive until the copy has been staged */
+  BL_HIP_CHECK(hipStreamSynchronize(stream));
+  BL_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
+  const int tb64 = (n_songs + 63) / 64;
+  hipLaunchKernelGGL(k_stats_init, dim3(tb64), dim3(64), 0, stream, d_stats, n_songs);
+  {
+    ProfScope ps(PK_SCAN, stream);
+    hipLaunchKernelGGL(k_pcm_scan, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm, d_songs,
+                       d_stats, d_hist);
+  }
+  hipLaunchKernelGGL(k_song_prep, dim3(tb64), dim3(64), 0, stream, d_songs, d_stats, n_songs,
+                     d_results);
+  hipLaunchKernelGGL(k_variance_wrap, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm, d_songs,
+                     d_stats);
+  hipLaunchKernelGGL(k_variance_wrap_finish, dim3(tb64), dim3(64), 0, stream, d_songs, d_stats,
+                     n_songs, d_results);
+  if (what & 1) {
+    ProfScope ps(PK_AMP, stream);
+    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, d_songs, d_stats, d_hist,
+                       d_results);
+  }
+  if (what & 2) {
+    {
+      ProfScope ps(PK_FREQ, stream);
+      hipLaunchKernelGGL(k_freq_frames, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream,
+                         d_pcm, d_songs, g.tb, d_partial);
+    }
+    ProfScope ps(PK_FREQ_FIN, stream);
+    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, gx_freq,
+                       d_results);
+  }
+  if (what & 4) {
+    {
+      ProfScope ps(PK_ENV, stream);
+      hipLaunchKernelGGL(k_env_windows, dim3(gx_env, n_songs), dim3(256), BL_ENV_LDS_BYTES, stream,
+                         d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc);
+    }
+    ProfScope ps(PK_TAIL, stream);
+    hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(64), 0, stream, d_songs, d_lc, n_songs, d_results,
+                       what);
+  }
+  BL_HIP_CHECK(hipGetLastError());
+  return BL_OK;
+}
+
+int analyze_device(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
+                   bl_amd_song_result *d_results, hipStream_t stream, int what) {
+  const int GROUP = 32768;
+  for (int b = 0; b < n_songs; b += GROUP) {
+    const int cnt = n_songs - b < GROUP ? n_songs - b : GROUP;
+    if (b) BL_HIP_CHECK(hipStreamSynchronize(stream)); /* workspace is reused */
+    if (analyze_group(d_pcm, h_desc + b, cnt, d_results + b, stream, what) != BL_OK)
+      return BL_UNEXPECTED;
+  }
+  return BL_OK;
+}
+
+} // namespace
+
+/* ========================================================================= */
+/* C-ABI                                                                      */
+
+extern "C" {
+
+int bl_amd_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+int bl_amd_init(int device) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  return init_locked(device);
+}
+
+int bld_ready(void) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.ready) {
+    if (hipSetDevice(g.device) != hipSuccess) return BL_UNEXPECTED;
+    return BL_OK;
+  }
+  return init_locked(0);
+}
+
+void bl_amd_profile(int enable) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  g.prof = enable != 0;
+}
+
+void bl_amd_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  prof_collect();
+  for (int k = 0; k < PK_COUNT; ++k) { g.prof_ms[k] = 0; g.prof_n[k] = 0; }
+}
+
+double bl_amd_profile_ms(const char *name, int *launches) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  prof_collect();
+  for (int k = 0; k < PK_COUNT; ++k)
+    if (!strcmp(name, kProfNames[k])) {
+      if (launches) *launches = g.prof_n[k];
+      return g.prof_ms[k];
+    }
+  if (launches) *launches = 0;
+  return -1.0;
+}
+
+int bl_amd_analyze_batch_device(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
+                                bl_amd_song_result *d_results, void *stream) {
+  if (n_songs <= 0 || !d_pcm || !h_desc || !d_results) return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  return analyze_device(d_pcm, h_desc, n_songs, d_results, static_cast<hipStream_t>(stream), 7);
+}
+
+int bl_amd_synth_pcm_device(int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
+                            uint32_t seed_base, uint32_t sample_rate, void *stream) {
+  if (n_songs <= 0 || !d_pcm || !h_desc) return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int GROUP = 32768;
+  for (int b = 0; b < n_songs; b += GROUP) {
+    const int cnt = n_songs - b < GROUP ? n_songs - b : GROUP;
+    std::vector<bl_dsong> hs;
+    long long env_total;
+    int max_n;
+    if (fill_songs(h_desc + b, cnt, hs, env_total, max_n) != BL_OK) return BL_UNEXPECTED;
+    if (b) BL_HIP_CHECK(hipStreamSynchronize(s));
+    if (ensure(g.songs, sizeof(bl_dsong) * cnt) != BL_OK) return BL_UNEXPECTED;
+    BL_HIP_CHECK(hipMemcpyAsync(g.songs.p, hs.data(), sizeof(bl_dsong) * cnt, hipMemcpyHostToDevice, s));
+    BL_HIP_CHECK(hipStreamSynchronize(s));
+    const int gx = grid_x_for(((long long)max_n + 255) / 256, cnt, 8);
+    hipLaunchKernelGGL(k_synth, dim3(gx, cnt), dim3(256), 0, s, d_pcm,
+                       static_cast<const bl_dsong *>(g.songs.p), seed_base + (uint32_t)b, sample_rate);
+    BL_HIP_CHECK(hipGetLastError());
+  }
+  return BL_OK;
+}
+
+static int matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin, int n_rows,
+                         float *d_out, void *stream, bool cosine) {
+  if (n <= 0 || n_rows <= 0 || row_begin < 0 || row_begin + n_rows > n || !d_vecs || !d_out)
+    return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float4 *v = reinterpret_cast<const float4 *>(d_vecs);
+  const int gx = (n + 1023) / 1024;
+  for (int r0 = 0; r0 < n_rows; r0 += 65535) {
+    const int cnt = n_rows - r0 < 65535 ? n_rows - r0 : 65535;
+    ProfScope ps(PK_DIST, s);
+    if (cosine)
+      hipLaunchKernelGGL(k_pairwise<true>, dim3(gx, cnt), dim3(256), 0, s, v, n, row_begin + r0,
+                         d_out + (size_t)r0 * n);
+    else
+      hipLaunchKernelGGL(k_pairwise<false>, dim3(gx, cnt), dim3(256), 0, s, v, n, row_begin + r0,
+                         d_out + (size_t)r0 * n);
+  }
+  BL_HIP_CHECK(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_amd_distance_matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin,
+                                  int n_rows, float *d_out, void *stream) {
+  return matrix_device(d_vecs, n, row_begin, n_rows, d_out, stream, false);
+}
+
+int bl_amd_cosine_matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin,
+                                int n_rows, float *d_out, void *stream) {
+  return matrix_device(d_vecs, n, row_begin, n_rows, d_out, stream, true);
+}
+
+static int matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out, bool cosine) {
+  if (n <= 0 || !h_vecs || !h_out) return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  void *dv = nullptr, *dout = nullptr;
+  BL_HIP_CHECK(hipMalloc(&dv, sizeof(struct force_vector_s) * (size_t)n));
+  if (hipMalloc(&dout, sizeof(float) * (size_t)n * n) != hipSuccess) { (void)hipFree(dv); return BL_UNEXPECTED; }
+  int rc = BL_UNEXPECTED;
+  if (hipMemcpy(dv, h_vecs, sizeof(struct force_vector_s) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+      matrix_device(static_cast<struct force_vector_s *>(dv), n, 0, n, static_cast<float *>(dout),
+                    nullptr, cosine) == BL_OK &&
+      hipMemcpy(h_out, dout, sizeof(float) * (size_t)n * n, hipMemcpyDeviceToHost) == hipSuccess)
+    rc = BL_OK;
+  (void)hipFree(dv);
+  (void)hipFree(dout);
+  return rc;
+}
+
+int bl_amd_distance_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out) {
+  return matrix_host(h_vecs, n, h_out, false);
+}
+int bl_amd_cosine_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out) {
+  return matrix_host(h_vecs, n, h_out, true);
+}
+
+/* ---- host-memory batch: pinned staging, copy/compute overlap on 2 streams ---- */
+int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samples,
+                              const int32_t *channels, const uint64_t *duration, int n_songs,
+                              bl_amd_song_result *h_results) {
+  if (n_songs <= 0 || !h_pcm || !n_samples || !channels || !duration || !h_results)
+    return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  for (int k = 0; k < 2; ++k)
+    if (!g.streams[k]) BL_HIP_CHECK(hipStreamCreateWithFlags(&g.streams[k], hipStreamNonBlocking));
+  if (ensure(g.results, sizeof(bl_amd_song_result) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
+  bl_amd_song_result *d_res = static_cast<bl_amd_song_result *>(g.results.p);
+
+  /* waves of songs of at most WAVE_BYTES of PCM each (one song may exceed it) */
+  const size_t WAVE_BYTES = (size_t)256 << 20;
+  int begin = 0, wave = 0;
+  int rc = BL_OK;
+  /* the shared scratch (stats, histograms, ...) is per launch group, so waves
+   * are serialised on the compute side by an event chain; copies still overlap */
+  hipEvent_t done[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; ++k) BL_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+  bool used[2] = {false, false};
+  while (begin < n_songs && rc == BL_OK) {
+    const int k = wave & 1;
+    size_t elems = 0;
+    int end = begin;
+    std::vector<bl_amd_song_desc> desc;
+    while (end < n_songs) {
+      const size_t need = ((size_t)n_samples[end] + 7) & ~(size_t)7;
+      if (end > begin && (elems + need) * 2 > WAVE_BYTES) break;
+      bl_amd_song_desc d;
+      d.pcm_offset = elems; d.n_samples = n_samples[end]; d.channels = channels[end];
+      d.duration = duration[end];
+      desc.push_back(d);
+      elems += need;
+      ++end;
+    }
+    const size_t bytes = elems * 2 + 64;
+    if (used[k]) { /* buffer k is free again once wave-2 has finished */
+      if (hipEventSynchronize(done[k]) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+    }
+    if (g.pinned_cap[k] < bytes) {
+      if (g.pinned[k]) (void)hipHostFree(g.pinned[k]);
+      g.pinned[k] = nullptr; g.pinned_cap[k] = 0;
+      if (hipHostMalloc(&g.pinned[k], bytes, hipHostMallocDefault) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+      g.pinned_cap[k] = bytes;
+    }
+    if (ensure(g.arena[k], bytes) != BL_OK) { rc = BL_UNEXPECTED; break; }
+    int16_t *stage = static_cast<int16_t *>(g.pinned[k]);
+    for (size_t i = 0; i < desc.size(); ++i) {
+      memcpy(stage + desc[i].pcm_offset, h_pcm[begin + i], (size_t)desc[i].n_samples * 2);
+      const size_t padded = ((size_t)desc[i].n_samples + 7) & ~(size_t)7;
+      for (size_t z = desc[i].n_samples; z < padded; ++z) stage[desc[i].pcm_offset + z] = 0;
+    }
+    hipStream_t s = g.streams[k];
+    if (hipMemcpyAsync(g.arena[k].p, stage, elems * 2, hipMemcpyHostToDevice, s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+    /* compute of this wave waits for the previous wave's compute (shared scratch) */
+    if (used[k ^ 1] && hipStreamWaitEvent(s, done[k ^ 1], 0) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+    if (analyze_device(static_cast<const int16_t *>(g.arena[k].p), desc.data(), (int)desc.size(),
+                       d_res + begin, s, 7) != BL_OK) { rc = BL_UNEXPECTED; break; }
+    if (hipEventRecord(done[k], s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+    used[k] = true;
+    begin = end;
+    ++wave;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (g.streams[k] && hipStreamSynchronize(g.streams[k]) != hipSuccess) rc = BL_UNEXPECTED;
+    (void)hipEventDestroy(done[k]);
+  }
+  if (rc == BL_OK &&
+      hipMemcpy(h_results, d_res, sizeof(bl_amd_song_result) * (size_t)n_songs, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = BL_UNEXPECTED;
+  return rc;
+}
+
+/* ---- helpers behind the reference-API shims of bl_api.c ---- */
+int bld_analyze_one_host(const int16_t *h_pcm, int n, int channels, uint64_t duration, int what,
+                         bl_amd_song_result *res) {
+  if (!h_pcm || !res) return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  const size_t elems = ((size_t)n + 7) & ~(size_t)7;
+  if (ensure(g.arena[0], elems * 2 + 64) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.results, sizeof(bl_amd_song_result)) != BL_OK) return BL_UNEXPECTED;
+  BL_HIP_CHECK(hipMemsetAsync(g.arena[0].p, 0, elems * 2, nullptr));
+  BL_HIP_CHECK(hipMemcpy(g.arena[0].p, h_pcm, (size_t)n * 2, hipMemcpyHostToDevice));
+  BL_HIP_CHECK(hipMemsetAsync(g.results.p, 0, sizeof(bl_amd_song_result), nullptr));
+  bl_amd_song_desc d;
+  d.pcm_offset = 0; d.n_samples = n; d.channels = channels; d.duration = duration ? duration : 1;
+  if (analyze_device(static_cast<const int16_t *>(g.arena[0].p), &d, 1,
+                     static_cast<bl_amd_song_result *>(g.results.p), nullptr, what) != BL_OK)
+    return BL_UNEXPECTED;
+  BL_HIP_CHECK(hipMemcpy(res, g.results.p, sizeof(bl_amd_song_result), hipMemcpyDeviceToHost));
+  return BL_OK;
+}
+
+int bld_mean_variance_host(const int16_t *h_pcm, int n, int have_mean, int mean_in, int *mean_out,
+                           int *variance_out) {
+  if (!h_pcm || n <= 0) return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  const size_t elems = ((size_t)n + 7) & ~(size_t)7;
+  if (ensure(g.arena[0], elems * 2 + 64) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.songs, sizeof(bl_dsong)) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.stats, sizeof(bl_dstats)) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.hist, sizeof(unsigned) * BL_HIST_BINS) != BL_OK) return BL_UNEXPECTED;
+  BL_HIP_CHECK(hipMemcpy(g.arena[0].p, h_pcm, (size_t)n * 2, hipMemcpyHostToDevice));
+  bl_dsong s;
+  memset(&s, 0, sizeof s);
+  s.n = n; s.channels = 1; s.duration = 1;
+  BL_HIP_CHECK(hipMemcpy(g.songs.p, &s, sizeof s, hipMemcpyHostToDevice));
+  BL_HIP_CHECK(hipMemsetAsync(g.hist.p, 0, sizeof(unsigned) * BL_HIST_BINS, nullptr));
+  bl_dstats *d_stats = static_cast<bl_dstats *>(g.stats.p);
+  const bl_dsong *d_songs = static_cast<const bl_dsong *>(g.songs.p);
+  const int gx = grid_x_for(((long long)n / 8 + 255) / 256, 1, 8);
+  hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(64), 0, nullptr, d_stats, 1);
+  hipLaunchKernelGGL(k_pcm_scan, dim3(gx, 1), dim3(256), 0, nullptr,
+                     static_cast<const int16_t *>(g.arena[0].p), d_songs, d_stats,
+                     static_cast<unsigned *>(g.hist.p));
+  bl_dstats st;
+  BL_HIP_CHECK(hipMemcpy(&st, d_stats, sizeof st, hipMemcpyDeviceToHost));
+  /* ref helpers.c:30-37 */
+  const int mean = have_mean ? mean_in : (int)(unsigned)(st.sum & 0xFFFFFFFFull) / n;
+  if (mean_out) *mean_out = mean;
+  if (variance_out) {
+    /* always the exact wrapping form (ref helpers.c:39-49) for the stand-alone helper */
+    st.mean = mean; st.wrap_pass = 1; st.wrap_acc = 0;
+    BL_HIP_CHECK(hipMemcpy(d_stats, &st, sizeof st, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_variance_wrap, dim3(gx, 1), dim3(256), 0, nullptr,
+                       static_cast<const int16_t *>(g.arena[0].p), d_songs, d_stats);
+    BL_HIP_CHECK(hipMemcpy(&st, d_stats, sizeof st, hipMemcpyDeviceToHost));
+    *variance_out = (int)(st.wrap_acc / n);
+  }
+  return BL_OK;
+}
+
+int bld_rect_filter_host(double *h_out, const double *h_in, int n, int width) {
+  if (!h_out || !h_in || n <= 0 || width <= 0 || width > n) return BL_UNEXPECTED;
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (ensure(g.misc, sizeof(double) * 2 * (size_t)n) != BL_OK) return BL_UNEXPECTED;
+  double *d_out = static_cast<double *>(g.misc.p), *d_in = d_out + n;
+  BL_HIP_CHECK(hipMemcpy(d_out, h_out, sizeof(double) * n, hipMemcpyHostToDevice));
+  BL_HIP_CHECK(hipMemcpy(d_in, h_in, sizeof(double) * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_rect_filter, dim3(1), dim3(1), 0, nullptr, d_out, d_in, n, width);
+  BL_HIP_CHECK(hipMemcpy(h_out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return BL_OK;
+}
+
+int bld_pair_host(const struct force_vector_s *a, const struct force_vector_s *b, int cosine,
+                  float *out) {
+  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (ensure(g.misc, 64) != BL_OK) return BL_UNEXPECTED;
+  const float4 va = make_float4(a->tempo, a->amplitude, a->frequency, a->attack);
+  const float4 vb = make_float4(b->tempo, b->amplitude, b->frequency, b->attack);
+  hipLaunchKernelGGL(k_pair, dim3(1), dim3(1), 0, nullptr, va, vb, cosine,
+                     static_cast<float *>(g.misc.p));
+  BL_HIP_CHECK(hipMemcpy(out, g.misc.p, sizeof(float), hipMemcpyDeviceToHost));
+  return BL_OK;
+}
+
+void bl_amd_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.ready) return;
+  (void)hipDeviceSynchronize();
+  prof_collect();
+  Buf *bufs[] = {&g.songs, &g.stats, &g.hist, &g.partial, &g.energies, &g.lc, &g.results, &g.misc,
+                 &g.arena[0], &g.arena[1]};
+  for (Buf *b : bufs) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr; b->cap = 0;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (g.pinned[k]) (void)hipHostFree(g.pinned[k]);
+    g.pinned[k] = nullptr; g.pinned_cap[k] = 0;
+    if (g.streams[k]) (void)hipStreamDestroy(g.streams[k]);
+    g.streams[k] = nullptr;
+  }
+  if (g.tables_mem) (void)hipFree(g.tables_mem);
+  g.tables_mem = nullptr;
+  g.ready = false;
+}
+
+} /* extern "C" */

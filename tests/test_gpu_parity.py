@@ -1,0 +1,202 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle on the same inputs.
+Bar: integer quantities bit-exact; f32 features within 1e-4 relative (north_star);
+in practice tempo/amplitude/attack are expected to be bit-identical and asserted so."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import bliss_amd
+from bliss_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+INTS = ("start", "end", "mean", "variance", "n_frames", "nb_frames", "n_windows", "beat",
+        "calm_or_loud")
+FLOATS = ("tempo", "amplitude", "frequency", "attack", "force")
+REL = 1e-4  # north_star tolerance for f32 features
+
+
+def check_song(got, ref, tag):
+    for k in INTS:
+        assert int(got[k]) == int(ref[k]), (tag, k, int(got[k]), int(ref[k]))
+    for k in FLOATS:
+        a, b = float(got[k]), float(ref[k])
+        assert abs(a - b) <= REL * max(abs(b), 1e-6), (tag, k, a, b)
+    # the exactly-ordered parts of the path: bit-identical expected
+    assert np.float32(got["amplitude"]) == np.float32(ref["amplitude"]), (tag, "amplitude bits")
+    assert np.float32(got["tempo"]) == np.float32(ref["tempo"]), (tag, "tempo bits")
+    assert abs(float(got["atk_sum"]) - ref["atk_sum"]) <= 1e-9 * abs(ref["atk_sum"]), (tag, "atk_sum")
+    assert int(got["status"]) == 0
+
+
+CASES = [  # (seed, rate, channels, seconds, extra_samples)
+    (11, 22050, 2, 11, 0),
+    (12, 44100, 2, 10, 0),
+    (13, 44100, 1, 12, 0),
+    (14, 22050, 1, 20, 333),     # n not a multiple of 8 / 512
+    (15, 22050, 2, 9, 1022),
+    (16, 8000, 1, 1, 0),         # 8000 samples: N = 30
+    (17, 5120, 1, 1, 0),         # shortest input the reference supports (N = 20)
+    (18, 48000, 2, 15, 6),
+]
+
+
+@pytest.fixture(scope="module")
+def batch(gpu_lib, oracle):
+    lengths = [r * c * s + e for (_, r, c, s, e) in CASES]
+    chans = [c for (_, _, c, _, _) in CASES]
+    durs = [s for (_, _, _, s, _) in CASES]
+    pcms = [oracle.synth(seed, r, c, n) for (seed, r, c, _, _), n in zip(CASES, lengths)]
+    # ragged edits the reference's trim / wrap corners are sensitive to
+    pcms[1][:777] = 0                 # leading digital silence  -> start = 777...
+    pcms[1][-4321:] = 0               # trailing silence
+    pcms[2][5000:9000] = 0            # silence in the middle (zero bin, not trimmed)
+    pcms[4] = (pcms[4].astype(np.int32) // 2 + 15000).astype(np.int16)  # |mean| > 13571: wrap pass
+    corpus = bliss_amd.DeviceCorpus(lengths, chans, durs)
+    for i, p in enumerate(pcms):
+        corpus.upload(i, p)
+    corpus.analyze()
+    return corpus.fetch(), pcms, chans, durs
+
+
+def test_batch_matches_oracle(batch, oracle):
+    got, pcms, chans, durs = batch
+    for i, p in enumerate(pcms):
+        ref = oracle.analyze(p, chans[i], durs[i])
+        check_song(got[i], ref, f"case{i}")
+    assert int(got[1]["start"]) >= 777 and int(got[1]["end"]) <= len(pcms[1]) - 4322
+    assert abs(int(got[4]["mean"])) > 13571  # exercised k_variance_wrap
+
+
+def test_host_batch_equals_device_batch(batch, gpu_lib):
+    got, pcms, chans, durs = batch
+    host = bliss_amd.analyze_batch_host(pcms, chans, durs)
+    for k in got.dtype.names:
+        assert np.array_equal(got[k], host[k]), k
+
+
+def test_device_synth_is_byte_identical(gpu_lib, oracle):
+    lengths = [22050 * 2 * 3 + 5, 44100 * 1 * 2]
+    corpus = bliss_amd.DeviceCorpus(lengths, [2, 1], [3, 2])
+    corpus.synth(seed_base=40, sample_rate=22050)
+    pcm = corpus.pcm.cpu().numpy()
+    for i, n in enumerate(lengths):
+        o = int(corpus.desc[i].pcm_offset)
+        assert np.array_equal(pcm[o:o + n], oracle.synth(40 + i, 22050, [2, 1][i], n))
+
+
+def test_reference_golden_through_bl_analyze(gpu_lib):
+    """ref tests/test_analyze.c:26-57 run against the drop-in library."""
+    song = _lib.BlSong()  # deliberately not initialised further (ref :27-28)
+    rc = gpu_lib.bl_analyze(os.path.join(HERE, "golden", "song.flac").encode(), C.byref(song))
+    assert rc == _lib.BL_CALM
+    gold = dict(force=-20.777929, tempo=-8.945454, amplitude=-10.641844, frequency=-10.136086,
+                attack=-15.560563)
+    assert abs(song.force - gold["force"]) <= 1e-5
+    for k in ("tempo", "amplitude", "frequency", "attack"):
+        assert abs(getattr(song.force_vector, k) - gold[k]) <= 1e-5, k
+    assert (song.channels, song.nSamples, song.sample_rate, song.bitrate,
+            song.nb_bytes_per_sample, song.duration) == (2, 488138, 22050, 233864, 2, 11)
+    n = song.nSamples
+    pcm = np.ctypeslib.as_array(C.cast(song.sample_array, C.POINTER(C.c_int16)), shape=(n,))
+    assert hashlib.md5(pcm.tobytes()).hexdigest() == "8a1bd824951c0433cc47fec5bf41d0a9"
+    # single analyzers of the public API on the same song (ref python/bliss/bl_song.py:179-199)
+    amp = gpu_lib.bl_amplitude_sort(C.byref(song))
+    frq = gpu_lib.bl_frequency_sort(C.byref(song))
+    env = _lib.EnvelopeResult()
+    gpu_lib.bl_envelope_sort(C.byref(song), C.byref(env))
+    assert amp == song.force_vector.amplitude and frq == song.force_vector.frequency
+    assert env.tempo == song.force_vector.tempo and env.attack == song.force_vector.attack
+    gpu_lib.bl_free_song(C.byref(song))
+
+
+def test_distance_file_and_errors(gpu_lib, tmp_path):
+    f = os.path.join(HERE, "golden", "song.flac").encode()
+    s1, s2 = _lib.BlSong(), _lib.BlSong()
+    d = gpu_lib.bl_distance_file(f, f, C.byref(s1), C.byref(s2))
+    assert d == 0.0
+    c = gpu_lib.bl_cosine_similarity_file(f, f, C.byref(s1), C.byref(s2))
+    assert abs(c - 1.0) < 1e-6
+    gpu_lib.bl_free_song(C.byref(s1)); gpu_lib.bl_free_song(C.byref(s2))
+    bad = str(tmp_path / "nope.flac").encode()
+    assert gpu_lib.bl_analyze(bad, C.byref(s1)) == _lib.BL_UNEXPECTED
+    assert gpu_lib.bl_distance_file(bad, f, C.byref(s1), C.byref(s2)) == float(_lib.BL_UNEXPECTED)
+
+
+def test_all_zero_song_is_flagged(gpu_lib):
+    res = bliss_amd.analyze_batch_host([np.zeros(22050 * 2, dtype=np.int16)], 2, 1)
+    assert int(res[0]["status"]) == _lib.BL_UNEXPECTED  # reference: unbounded trim loop
+
+
+def test_distance_matrix_bit_exact(gpu_lib, oracle):
+    rng = np.random.default_rng(5)
+    v = (rng.standard_normal((1000, 4)) * 10).astype(np.float32)
+    dm = bliss_amd.distance_matrix(v)
+    assert np.array_equal(dm, oracle.distance_matrix(v))
+    cm = bliss_amd.cosine_matrix(v[:200])
+    ref = np.array([[oracle.cosine(a, b) for b in v[:200]] for a in v[:200]], dtype=np.float32)
+    assert np.array_equal(cm, ref)
+    a, b = _lib.ForceVector(*v[0]), _lib.ForceVector(*v[1])
+    assert gpu_lib.bl_distance(a, b) == oracle.distance(v[0], v[1]) == dm[0, 1]
+    assert gpu_lib.bl_cosine_similarity(a, b) == oracle.cosine(v[0], v[1])
+
+
+def test_distance_matrix_full_size_properties(gpu_lib):
+    """BASELINE config 4 (N = 10 000): size-independent properties + sampled exactness."""
+    rng = np.random.default_rng(6)
+    v = (rng.standard_normal((10000, 4)) * 8).astype(np.float32)
+    dm = bliss_amd.distance_matrix(v)
+    assert dm.shape == (10000, 10000)
+    assert np.array_equal(dm, dm.T) and not np.any(np.diag(dm))
+    i = rng.integers(0, 10000, 2000); j = rng.integers(0, 10000, 2000)
+    d = v[i] - v[j]
+    s = d[:, 0] * d[:, 0]
+    for k in (1, 2, 3):
+        s = (s + d[:, k] * d[:, k]).astype(np.float32)
+    assert np.array_equal(dm[i, j], np.sqrt(s).astype(np.float32))
+    # triangle inequality on a sample (f32 slack)
+    k = rng.integers(0, 10000, 2000)
+    assert np.all(dm[i, j] <= dm[i, k] + dm[k, j] + 1e-3)
+
+
+def test_helper_symbols(gpu_lib, oracle):
+    pcm = oracle.synth(3, 22050, 2, 100001)
+    pcm = (pcm.astype(np.int32) + 20000).clip(-32768, 32767).astype(np.int16)  # int32 v*v wrap
+    p = pcm.ctypes.data_as(C.POINTER(C.c_int16))
+    m = gpu_lib.bl_mean(p, pcm.size)
+    assert m == oracle.mean(pcm)
+    assert gpu_lib.bl_variance(p, pcm.size, m) == oracle.variance(pcm, m)
+    rng = np.random.default_rng(1)
+    inp = rng.standard_normal(500)
+    old = rng.standard_normal(500)
+    out = old.copy()
+    dp = C.POINTER(C.c_double)
+    gpu_lib.bl_rectangular_filter(out.ctypes.data_as(dp), inp.ctypes.data_as(dp), 500, 19)
+    assert np.array_equal(out, oracle.rect_filter(old, inp, 19))
+
+
+def test_window_energies_and_full_size_sample(gpu_lib, oracle):
+    """BASELINE config 2 shape at reduced count (64 x 30 s, 44.1 kHz stereo): every song's
+    integers + floats against the oracle for a sample, and batch-order independence."""
+    n = 44100 * 2 * 30
+    corpus = bliss_amd.DeviceCorpus([n] * 64, 2, 30)
+    corpus.synth(seed_base=1000, sample_rate=44100)
+    corpus.analyze()
+    got = corpus.fetch()
+    assert np.all(got["status"] == 0) and np.all(got["n_windows"] == 10332)
+    pcm = corpus.pcm.cpu().numpy()
+    for i in (0, 17, 63):
+        o = int(corpus.desc[i].pcm_offset)
+        ref = oracle.analyze(pcm[o:o + n], 2, 30)
+        check_song(got[i], ref, f"s30[{i}]")
+    # same songs analysed alone give identical records (no cross-song state)
+    solo = bliss_amd.DeviceCorpus([n], 2, 30)
+    solo.synth(seed_base=1017, sample_rate=44100)
+    solo.analyze()
+    one = solo.fetch()[0]
+    for k in got.dtype.names:
+        assert one[k] == got[17][k], k

@@ -1,0 +1,26 @@
+"""Runs the device arithmetic codelets (bl_fft.h, bl_tail.h are __host__ __device__) on the
+CPU: the FFT lane code against a long-double DFT, the streaming envelope tail against the
+oracle (bit-exact beat / atk_sum, including the shortest arrays the reference supports)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tests", "host")
+
+
+def _run(tmp_path, src, extra):
+    exe = str(tmp_path / (src + ".bin"))
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(HOST, src)] + extra
+                   + ["-o", exe, "-lm"], check=True, stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stdout
+    assert out.stdout.strip().endswith("OK"), out.stdout
+
+
+def test_fft_lane_code(tmp_path):
+    _run(tmp_path, "test_fft_host.cpp", [])
+
+
+def test_streaming_tail_matches_oracle(tmp_path):
+    orc = [os.path.join(ROOT, "oracle", f) for f in ("bliss_oracle.c", "orc_fft.c", "orc_synth.c")]
+    _run(tmp_path, "test_tail_host.cpp", ["-x", "c"] + orc)

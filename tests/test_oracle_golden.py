@@ -1,0 +1,76 @@
+"""Pins the CPU oracle on the reference's own goldens (ref tests/test_analyze.c:26-57,
+tests/test_decode.c:12-27) using the reference's fixture audio/song.flac, decoded by the
+product's host ingest (bl_audio_decode; no GPU involved)."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from bliss_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FLAC = os.path.join(HERE, "golden", "song.flac")
+
+# ref tests/test_analyze.c:30-35, tolerance EPSILON = 1e-5 absolute (:5-11)
+GOLD = dict(force=-20.777929, tempo=-8.945454, amplitude=-10.641844, frequency=-10.136086,
+            attack=-15.560563)
+MD5 = "8a1bd824951c0433cc47fec5bf41d0a9"  # ref tests/test_decode.c:16-17
+
+
+@pytest.fixture(scope="module")
+def decoded(lib):
+    song = _lib.BlSong()
+    assert lib.bl_audio_decode(FLAC.encode(), C.byref(song)) == _lib.BL_OK
+    n = song.nSamples
+    pcm = np.ctypeslib.as_array(C.cast(song.sample_array, C.POINTER(C.c_int16)), shape=(n,)).copy()
+    meta = dict(channels=song.channels, nSamples=n, sample_rate=song.sample_rate,
+                bitrate=song.bitrate, nb_bytes_per_sample=song.nb_bytes_per_sample,
+                duration=song.duration, artist=song.artist, title=song.title, album=song.album,
+                tracknumber=song.tracknumber, genre=song.genre)
+    lib.bl_free_song(C.byref(song))
+    assert not song.sample_array and not song.artist
+    return pcm, meta
+
+
+def test_decode_md5_and_metadata(decoded):
+    pcm, meta = decoded
+    assert hashlib.md5(pcm.tobytes()).hexdigest() == MD5
+    # ref tests/test_analyze.c:36-55
+    assert meta["channels"] == 2 and meta["nSamples"] == 488138 and meta["sample_rate"] == 22050
+    assert meta["bitrate"] == 233864 and meta["nb_bytes_per_sample"] == 2 and meta["duration"] == 11
+    assert (meta["artist"], meta["title"], meta["album"], meta["tracknumber"], meta["genre"]) == \
+        (b"David TMX", b"Renaissance", b"Renaissance", b"02", b"Pop")
+
+
+def test_oracle_reproduces_reference_goldens(decoded, oracle):
+    pcm, meta = decoded
+    r = oracle.analyze(pcm, 2, 11)
+    for k, want in GOLD.items():
+        assert abs(r[k] - want) <= 1e-5, (k, r[k], want)
+    assert r["calm_or_loud"] == 1  # BL_CALM
+    assert r["beat"] == 59 and r["nb_frames"] == 1906
+
+
+def test_decode_rejects_garbage(lib, tmp_path):
+    p = tmp_path / "x.bin"
+    p.write_bytes(b"not audio at all" * 10)
+    song = _lib.BlSong()
+    assert lib.bl_audio_decode(str(p).encode(), C.byref(song)) == _lib.BL_UNEXPECTED
+    assert lib.bl_audio_decode(b"/nonexistent/file.flac", C.byref(song)) == _lib.BL_UNEXPECTED
+
+
+def test_wav_roundtrip(lib, tmp_path, oracle):
+    import wave
+    pcm = oracle.synth(7, 22050, 2, 22050 * 2 * 3)
+    p = tmp_path / "s.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(22050)
+        w.writeframes(pcm.tobytes())
+    song = _lib.BlSong()
+    assert lib.bl_audio_decode(str(p).encode(), C.byref(song)) == _lib.BL_OK
+    got = np.ctypeslib.as_array(C.cast(song.sample_array, C.POINTER(C.c_int16)), shape=(song.nSamples,))
+    assert np.array_equal(got, pcm) and song.duration == 3 and song.channels == 2
+    assert song.title == b"<no title>" and song.tracknumber == b""  # ref src/decode.c:263-308
+    lib.bl_free_song(C.byref(song))
