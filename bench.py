@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the bliss analysis hot path on MI355X.
+
+One *step* = one pass of the hot path over one resident batch of synthetic decoded
+songs: pcm_scan -> amplitude / frequency / envelope kernels -> force vectors
+(bl_analyze after decode, ref src/analyze.c:40-80), then — as BASELINE.json's
+batch-of-songs mode asks — an all-gather of the 16-byte force vectors over RCCL and this
+rank's row block of the bl_distance matrix (ref src/analyze.c:96-100).
+
+Workload: BASELINE.json configs[2] shape — 3-minute 44.1 kHz s16 stereo buffers
+(15 876 000 interleaved int16 each), `--songs-per-gpu` of them resident in HBM per rank
+(default: the configs[2] shard of 8 192 per GPU when it fits, else the largest count that
+does; the count used is printed in config.workload).  Songs are sharded by index across
+ranks (weak scaling, no data-path collective other than the vector all-gather).
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+ --master-port P bench.py --gpus N --steps K --warmup W`.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SONG_SAMPLES = 44100 * 2 * 180          # S180 of SURVEY.md §8
+SONG_SECONDS = 180
+SAMPLE_RATE = 44100
+HBM_PEAK_GBS = 8000.0                   # spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBS = 6290.0             # measured float4 copy, same guide
+FP64_VALU_PEAK_TFLOPS = 78.6            # spec (FMA = 2 flop); the faithful path's real ceiling
+
+
+def shard_counts(total, world):
+    """songs per rank for a corpus of `total` songs (equal-length songs: contiguous blocks)."""
+    base, rem = divmod(total, world)
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded
+    sample of the same workload: one process per core (not threads: the reference is not
+    thread re-entrant — FFTW planner globals, ref src/tempo_atk_sort.c:94,294-295), each
+    analysing `per_proc` synthetic 3-minute songs.  Like the GPU number, the rate counts
+    analysis time only (orc_cli times orc_analyze_pcm, not the integer synthesis):
+    value = sum over processes of songs_p / analysis_seconds_p, all processes concurrent."""
+    from tests.oracle_py import build_oracle
+    build_oracle()
+    cli = os.path.join(ROOT, "oracle", "orc_cli")
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    out = subprocess.run([cli, "time", "9000", str(SAMPLE_RATE), "2", str(SONG_SECONDS), "1"],
+                         stdout=subprocess.PIPE, text=True, check=True)
+    one = json.loads(out.stdout.strip().splitlines()[-1])
+    wall_one = time.time() - t0
+    # all cores busy (SMT) runs ~2-3x slower per process than the calibration
+    per_proc = max(1, min(4, int(seconds_budget / (3.0 * max(wall_one, 1e-3)))))
+    t0 = time.time()
+    procs = [subprocess.Popen([cli, "time", str(9100 + 16 * i), str(SAMPLE_RATE), "2",
+                               str(SONG_SECONDS), str(per_proc)], stdout=subprocess.PIPE, text=True)
+             for i in range(cores)]
+    rate = 0.0
+    done = 0
+    for p in procs:
+        o, _ = p.communicate()
+        try:
+            r = json.loads(o.strip().splitlines()[-1])
+            rate += r["songs"] / r["seconds"]
+            done += r["songs"]
+        except Exception:
+            pass
+    wall = time.time() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": rate, "unit": "songs/s", "cores": cores, "kind": "port",
+            "sample": f"{done} synthetic 3-min 44.1 kHz s16 stereo songs, {per_proc} per process, "
+                      f"{cores} concurrent processes (one per hardware thread), analysis time only; "
+                      f"wall {wall:.1f} s incl. synthesis; 1 core alone: {one['songs_per_s']:.3f} songs/s",
+            "cpu_model": model, "one_core_songs_per_s": one["songs_per_s"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--songs-per-gpu", type=int, default=0,
+                    help="0 = configs[2] shard (8192) if it fits in HBM, else the largest count that does")
+    ap.add_argument("--seconds", type=int, default=SONG_SECONDS, help="song length (default 180)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import bliss_amd
+    from bliss_amd import _lib
+    lib = bliss_amd.load()
+    assert lib.bl_amd_init(local_rank) == 0
+
+    song_samples = SAMPLE_RATE * 2 * args.seconds
+    song_bytes = 2 * song_samples
+    # per-song scratch: 12 B per envelope slot + histogram + small records
+    scratch_per_song = 12 * (2 * (song_samples // 512)) + 4 * 4096 + 4096
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    want = args.songs_per_gpu if args.songs_per_gpu > 0 else 8192
+    margin = 8 << 30
+    fit = int((free_b - margin) // (song_bytes + scratch_per_song + 16 + 4 * want * world))
+    songs = want
+    capped = False
+    if songs > fit:
+        songs = max(1, 1 << (max(fit, 1).bit_length() - 1))
+        capped = True
+    if world > 1:  # every rank uses the smallest count any rank can hold
+        t = torch.tensor([songs], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        songs = int(t.item())
+    total_songs = songs * world
+    my_first = rank * songs
+
+    corpus = bliss_amd.DeviceCorpus([song_samples] * songs, 2, args.seconds, device=f"cuda:{local_rank}")
+    corpus.synth(seed_base=my_first, sample_rate=SAMPLE_RATE)
+    torch.cuda.synchronize(dev)
+
+    all_vecs = torch.empty((total_songs, 4), dtype=torch.float32, device=dev)
+    rows = torch.empty((songs, total_songs), dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        corpus.analyze()
+        mine = corpus.force_vectors()
+        if world > 1:
+            dist.all_gather_into_tensor(all_vecs, mine)
+        else:
+            all_vecs.copy_(mine)
+        rc = lib.bl_amd_distance_matrix_device(C.c_void_p(all_vecs.data_ptr()), total_songs, my_first,
+                                               songs, C.c_void_p(rows.data_ptr()), stream)
+        assert rc == 0
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.bl_amd_profile_reset()
+    lib.bl_amd_profile(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.bl_amd_profile(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time of the timed region (HIP events on the launch stream)
+    kern = {}
+    for name in ("pcm_scan", "amp_finish", "freq_frames", "freq_finish", "env_windows", "env_tail",
+                 "distance"):
+        n = C.c_int(0)
+        ms = lib.bl_amd_profile_ms(name.encode(), C.byref(n))
+        kern[name] = {"ms_total": ms, "launches": n.value,
+                      "ms_avg": (ms / n.value) if n.value else None}
+
+    res = corpus.fetch()
+    ok = bool(np.all(res["status"] == 0) and np.all(np.isfinite(res["force"])))
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_songs * args.steps / elapsed
+        alg_bytes_song = song_bytes + 16          # 2n read + 16 written
+        dom = kern["env_windows"]
+        launch_bytes = alg_bytes_song * songs     # one env_windows launch covers this rank's batch
+        roof = None
+        if dom["ms_avg"]:
+            ach = launch_bytes / (dom["ms_avg"] * 1e-3) / 1e9
+            # faithful-arithmetic count of the kernel: ~75 f64 VALU instructions per sample
+            # (normalise 4, FIR 26, FFT+split 33, f32-ordered sum 3, log 0.1)
+            f64_rate = 75.0 * song_samples * songs / (dom["ms_avg"] * 1e-3) / 1e12
+            roof = {"bound": "hbm", "kernel": "k_env_windows", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "frac_of_measured_copy_peak": ach / HBM_ACHIEVABLE_GBS,
+                    "ms_avg_launch": dom["ms_avg"], "launches": dom["launches"],
+                    "algorithmic_bytes_per_launch": launch_bytes,
+                    "secondary_f64_valu": {"achieved_Tinstr_per_s": f64_rate,
+                                           "peak_Tinstr_per_s": FP64_VALU_PEAK_TFLOPS / 2,
+                                           "frac": f64_rate / (FP64_VALU_PEAK_TFLOPS / 2)}}
+        whole_path_gbs = value / world * alg_bytes_song / 1e9
+
+        # BASELINE config 4: standalone 10 000 x 10 000 bl_distance matrix on one GPU
+        g = torch.Generator(device="cpu").manual_seed(4)
+        v10 = (torch.randn((10000, 4), generator=g) * 8).to(dev)
+        m10 = torch.empty((10000, 10000), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            lib.bl_amd_distance_matrix_device(C.c_void_p(v10.data_ptr()), 10000, 0, 10000,
+                                              C.c_void_p(m10.data_ptr()), stream)
+        torch.cuda.synchronize(dev)
+        reps = 10
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            lib.bl_amd_distance_matrix_device(C.c_void_p(v10.data_ptr()), 10000, 0, 10000,
+                                              C.c_void_p(m10.data_ptr()), stream)
+        torch.cuda.synchronize(dev)
+        dm_s = (time.perf_counter() - t1) / reps
+        dm_bytes = 4 * 10000 * 10000 + 16 * 10000
+
+        line = {
+            "metric": "songs/sec bl_analyze (3-min 44.1kHz s16) + 10k x 10k distance-matrix sec",
+            "value": value, "unit": "songs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2] shape: {songs} synthetic {args.seconds}-s 44.1 kHz s16 "
+                                   f"stereo songs resident per GPU ({songs * song_bytes / 1e9:.1f} GB PCM/GPU"
+                                   + (", capped by free HBM" if capped else "")
+                                   + f"), {total_songs} songs total, sharded by song; step = analyze + "
+                                     "all-gather of force vectors + row-block distance matrix",
+                       "songs_per_gpu": songs, "song_samples": song_samples, "parallelism": f"shard{world}",
+                       "generator": "integer-only device synth, seeds = global song index"},
+            "distance_matrix_10k_s": dm_s,
+            "distance_matrix_10k_gbs": dm_bytes / dm_s / 1e9,
+            "distance_matrix_10k_frac_hbm": dm_bytes / dm_s / 1e9 / HBM_PEAK_GBS,
+            "whole_path_algorithmic_gbs_per_gpu": whole_path_gbs,
+            "whole_path_frac_hbm": whole_path_gbs / HBM_PEAK_GBS,
+            "kernels_ms": kern, "results_ok": ok,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline must never sink the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "songs/s", "cores": os.cpu_count(),
+                                        "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

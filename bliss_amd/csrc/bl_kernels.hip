@@ -57,7 +57,7 @@ struct bl_dsong {
   int n_frames;  /* (n / channels) / 512              ref frequency_sort.c:50 */
   int nb_frames; /* 2 * floor(n / 512)                ref tempo_atk_sort.c:63-64 */
   int n_windows; /* nb_frames - 2 windows of hop 256  ref tempo_atk_sort.c:66-67,120 */
-  int pad;
+  int part_off;  /* first partial-spectrum slot of this song (256 frames per slot) */
 };
 
 struct bl_dstats {
@@ -322,6 +322,7 @@ struct bl_tables {
   double log101;
 };
 
+#define BL_FREQ_CHUNK 256 /* frames per partial spectrum */
 #define BL_FREQ_LDS_BYTES                                                              \
   (16 * BL_FFT_XCH_ELEMS * 8 + 16 * BL_FFT_PAR_ELEMS * 8 + 2 * 256 * 8 + 512 * 4)
 
@@ -343,75 +344,84 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
   hann[tid + 256] = tb.hann[tid + 256];
   __syncthreads();
 
-  float a_own[8], a_mir[8], a_mid = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { a_own[k] = 0.f; a_mir[k] = 0.f; }
   c2f *gx = xch + g * BL_FFT_XCH_ELEMS, *gp = par + g * BL_FFT_PAR_ELEMS;
-
-  for (int base = blockIdx.x * 16; base < sg.n_frames; base += gridDim.x * 16) {
-    const int f = base + g;
-    const bool active = f < sg.n_frames;
-    float re[16], im[16];
-    if (active && sg.channels == 2) {
-      /* ref :69-75: (float)((L + R) / 2) * hann[d], integer average truncates */
-      const uint2 *q = reinterpret_cast<const uint2 *>(p + (size_t)f * 1024);
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) {
-        const uint2 w = q[16 * m1 + l];
-        const int d = 32 * m1 + 2 * l;
-        const int s0 = ((int)(short)(w.x & 0xFFFFu) + (int)(short)(w.x >> 16)) / 2;
-        const int s1 = ((int)(short)(w.y & 0xFFFFu) + (int)(short)(w.y >> 16)) / 2;
-        re[m1] = (float)s0 * hann[d];
-        im[m1] = (float)s1 * hann[d + 1];
-      }
-    } else if (active) { /* ref :76-80 */
-      const unsigned *q = reinterpret_cast<const unsigned *>(p + (size_t)f * 512);
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) {
-        const unsigned w = q[16 * m1 + l];
-        const int d = 32 * m1 + 2 * l;
-        re[m1] = (float)(int)(short)(w & 0xFFFFu) * hann[d];
-        im[m1] = (float)(int)(short)(w >> 16) * hann[d + 1];
-      }
-    } else {
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) { re[m1] = 0.f; im[m1] = 0.f; }
-    }
-    bl_fft512_phaseA<float>(l, re, im, tw256, gx);
-    __syncthreads();
-    bl_fft512_phaseB<float>(l, re, im, gx, gp);
-    __syncthreads();
-    float own[8], mir[8], mid;
-    bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
-    if (active) { /* ref :88-93: power_spectrum[d] += re*re + im*im */
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { a_own[k] += own[k]; a_mir[k] += mir[k]; }
-      a_mid += mid;
-    }
-    __syncthreads();
-  }
-  /* fold the 16 groups of the block in a fixed order */
   float *red = reinterpret_cast<float *>(smem); /* [16][256], aliases xch */
+  /* The frames of a song are cut into fixed chunks of BL_FREQ_CHUNK (independent of
+   * the launch geometry), so a song's result never depends on what else is in the
+   * batch: within a chunk each 16-lane group adds its frames in frame order, the 16
+   * groups are folded in group order, k_freq_finish adds the chunks in chunk order. */
+  const int parts = (sg.n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
+  for (int chunk = blockIdx.x; chunk < parts; chunk += gridDim.x) {
+    float a_own[8], a_mir[8], a_mid = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    red[g * 256 + l + 16 * k] = a_own[k];
-    if (l + 16 * k != 0) red[g * 256 + 256 - l - 16 * k] = a_mir[k];
+    for (int k = 0; k < 8; ++k) { a_own[k] = 0.f; a_mir[k] = 0.f; }
+    for (int it = 0; it < BL_FREQ_CHUNK / 16; ++it) {
+      const int f = chunk * BL_FREQ_CHUNK + it * 16 + g;
+      const bool active = f < sg.n_frames;
+      float re[16], im[16];
+      if (active && sg.channels == 2) {
+        /* ref :69-75: (float)((L + R) / 2) * hann[d], integer average truncates */
+        const uint2 *q = reinterpret_cast<const uint2 *>(p + (size_t)f * 1024);
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) {
+          const uint2 w = q[16 * m1 + l];
+          const int d = 32 * m1 + 2 * l;
+          const int s0 = ((int)(short)(w.x & 0xFFFFu) + (int)(short)(w.x >> 16)) / 2;
+          const int s1 = ((int)(short)(w.y & 0xFFFFu) + (int)(short)(w.y >> 16)) / 2;
+          re[m1] = (float)s0 * hann[d];
+          im[m1] = (float)s1 * hann[d + 1];
+        }
+      } else if (active) { /* ref :76-80 */
+        const unsigned *q = reinterpret_cast<const unsigned *>(p + (size_t)f * 512);
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) {
+          const unsigned w = q[16 * m1 + l];
+          const int d = 32 * m1 + 2 * l;
+          re[m1] = (float)(int)(short)(w & 0xFFFFu) * hann[d];
+          im[m1] = (float)(int)(short)(w >> 16) * hann[d + 1];
+        }
+      } else {
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) { re[m1] = 0.f; im[m1] = 0.f; }
+      }
+      bl_fft512_phaseA<float>(l, re, im, tw256, gx);
+      __syncthreads();
+      bl_fft512_phaseB<float>(l, re, im, gx, gp);
+      __syncthreads();
+      float own[8], mir[8], mid;
+      bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
+      if (active) { /* ref :88-93: power_spectrum[d] += re*re + im*im */
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a_own[k] += own[k]; a_mir[k] += mir[k]; }
+        a_mid += mid;
+      }
+      __syncthreads();
+    }
+    /* fold the 16 groups of the block in a fixed order */
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[g * 256 + l + 16 * k] = a_own[k];
+      if (l + 16 * k != 0) red[g * 256 + 256 - l - 16 * k] = a_mir[k];
+    }
+    if (l == 0) red[g * 256 + 128] = a_mid;
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) acc += red[gg * 256 + tid];
+    partial[((size_t)sg.part_off + chunk) * 256 + tid] = acc;
+    __syncthreads();
   }
-  if (l == 0) red[g * 256 + 128] = a_mid;
-  __syncthreads();
-  float acc = 0.f;
-#pragma unroll
-  for (int gg = 0; gg < 16; ++gg) acc += red[gg * 256 + tid];
-  partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ partial, int parts,
+__global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ partial,
+                                                     const bl_dsong *__restrict__ songs,
                                                      bl_amd_song_result *res) {
   __shared__ float ps[256];
   __shared__ float wmax[4];
   const int d = threadIdx.x, song = blockIdx.x;
   float acc = 0.f;
-  const float *pp = partial + (size_t)song * parts * 256 + d;
+  const int parts = (songs[song].n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
+  const float *pp = partial + (size_t)songs[song].part_off * 256 + d;
   for (int k = 0; k < parts; ++k) acc += pp[(size_t)k * 256];
   /* ref :97-102: sqrt(ps / 512), peak over d = 1..256 (ps[256] is 0) */
   float v = d == 0 ? 0.f : (float)sqrt((double)(acc / 512));
@@ -668,7 +678,7 @@ __device__ __forceinline__ float bl_dist(const float4 a, const float4 b) {
   /* ref analyze.c:96-100: f32 throughout, left-to-right, sqrt correctly rounded */
   const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
   const float s = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-  return __fsqrt_rn(s);
+  return sqrtf(s); /* correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the 1-ulp native op */
 }
 
 __device__ __forceinline__ float bl_cos(const float4 a, const float4 b) {
@@ -896,10 +906,11 @@ void prof_collect() {
 /* host mirror of the per-song geometry (integer work of ref tempo_atk_sort.c:63-67,
  * frequency_sort.c:50) */
 int fill_songs(const bl_amd_song_desc *desc, int n_songs, std::vector<bl_dsong> &out,
-               long long &env_total, int &max_n) {
+               long long &env_total, int &max_n, long long *parts_total = nullptr) {
   out.resize(n_songs);
   env_total = 0;
   max_n = 0;
+  long long parts = 0;
   for (int i = 0; i < n_songs; ++i) {
     const bl_amd_song_desc &d = desc[i];
     if (d.n_samples < 5120 || (d.channels != 1 && d.channels != 2) || d.duration == 0 ||
@@ -920,10 +931,12 @@ int fill_songs(const bl_amd_song_desc *desc, int n_songs, std::vector<bl_dsong> 
     s.nb_frames = (d.n_samples - (d.n_samples % 512)) * 2 / 512;
     s.n_windows = s.nb_frames - 2;
     s.env_off = env_total;
-    s.pad = 0;
+    s.part_off = (int)parts;
+    parts += (s.n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
     env_total += s.nb_frames;
     if (d.n_samples > max_n) max_n = d.n_samples;
   }
+  if (parts_total) *parts_total = parts;
   return BL_OK;
 }
 
@@ -944,17 +957,18 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   std::vector<bl_dsong> hs;
   long long env_total = 0;
   int max_n = 0;
-  if (fill_songs(h_desc, n_songs, hs, env_total, max_n) != BL_OK) return BL_UNEXPECTED;
+  long long parts_total = 0;
+  if (fill_songs(h_desc, n_songs, hs, env_total, max_n, &parts_total) != BL_OK) return BL_UNEXPECTED;
 
   const int max_frames = (max_n / 512);
   const int gx_scan = grid_x_for(((long long)max_n / 8 + 255) / 256, n_songs, 8);
-  const int gx_freq = grid_x_for((max_frames + 15) / 16 + 1, n_songs, 6);
+  const int gx_freq = grid_x_for((max_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK, n_songs, 6);
   const int gx_env = grid_x_for((2 * max_frames + BL_TILE_W - 1) / BL_TILE_W, n_songs, 6);
 
   if (ensure(g.songs, sizeof(bl_dsong) * n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.stats, sizeof(bl_dstats) * n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.hist, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.partial, sizeof(float) * 256 * (size_t)gx_freq * n_songs) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.partial, sizeof(float) * 256 * (size_t)(parts_total + 1)) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.energies, sizeof(float) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.lc, sizeof(double) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
 
@@ -995,7 +1009,7 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
                          d_pcm, d_songs, g.tb, d_partial);
     }
     ProfScope ps(PK_FREQ_FIN, stream);
-    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, gx_freq,
+    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, d_songs,
                        d_results);
   }
   if (what & 4) {

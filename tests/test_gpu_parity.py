@@ -55,7 +55,10 @@ def batch(gpu_lib, oracle):
     pcms[1][:777] = 0                 # leading digital silence  -> start = 777...
     pcms[1][-4321:] = 0               # trailing silence
     pcms[2][5000:9000] = 0            # silence in the middle (zero bin, not trimmed)
-    pcms[4] = (pcms[4].astype(np.int32) // 2 + 15000).astype(np.int16)  # |mean| > 13571: wrap pass
+    # DC offset on a long song: bl_mean's int32 accumulator wraps (ref src/helpers.c:31-36)
+    pcms[4] = (pcms[4].astype(np.int32) // 2 + 15000).astype(np.int16)
+    # DC offset on a short song: |mean| > 13571 -> int32 (v*v) wraps, k_variance_wrap path
+    pcms[5] = (pcms[5].astype(np.int32) // 2 + 15000).astype(np.int16)
     corpus = bliss_amd.DeviceCorpus(lengths, chans, durs)
     for i, p in enumerate(pcms):
         corpus.upload(i, p)
@@ -69,7 +72,8 @@ def test_batch_matches_oracle(batch, oracle):
         ref = oracle.analyze(p, chans[i], durs[i])
         check_song(got[i], ref, f"case{i}")
     assert int(got[1]["start"]) >= 777 and int(got[1]["end"]) <= len(pcms[1]) - 4322
-    assert abs(int(got[4]["mean"])) > 13571  # exercised k_variance_wrap
+    assert int(got[4]["mean"]) == 4206          # the wrapped int32 sum, as the reference computes it
+    assert abs(int(got[5]["mean"])) > 13571     # exercised k_variance_wrap
 
 
 def test_host_batch_equals_device_batch(batch, gpu_lib):
