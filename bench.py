@@ -60,7 +60,7 @@ def cpu_baseline(seconds_budget=25.0):
     one = json.loads(out.stdout.strip().splitlines()[-1])
     wall_one = time.time() - t0
     # all cores busy (SMT) runs ~2-3x slower per process than the calibration
-    per_proc = max(1, min(4, int(seconds_budget / (3.0 * max(wall_one, 1e-3)))))
+    per_proc = max(1, min(2, int(seconds_budget / (6.0 * max(wall_one, 1e-3)))))
     t0 = time.time()
     procs = [subprocess.Popen([cli, "time", str(9100 + 16 * i), str(SAMPLE_RATE), "2",
                                str(SONG_SECONDS), str(per_proc)], stdout=subprocess.PIPE, text=True)
