@@ -81,6 +81,7 @@ SYMBOLS = {
     "bl_amd_profile": (None, [C.c_int]),
     "bl_amd_profile_reset": (None, []),
     "bl_amd_profile_ms": (C.c_double, [C.c_char_p, _P(C.c_int)]),
+    "bl_amd_last_energies": (C.c_longlong, [_P(C.c_float), C.c_longlong]),
     "bl_amd_shutdown": (None, []),
 }
 

@@ -139,41 +139,76 @@ BL_HD void bl_fft512_phaseB(int k1, T (&re)[16], T (&im)[16], const bl_c2<T> *xc
 }
 
 /*
- * Phase C (per lane k1, after a barrier): power of the real-input spectrum.
+ * Power of the real-input spectrum from a lane's own half row and its partner's.
+ * re/im: Z[k1 + 16*k0] at position bl_pos16(k0); pr/pi[k0] (k0 = 0..7): Z[256 - k],
+ * k = k1 + 16*k0, i.e. the partner lane's register 15-k0 (lane 0: its own 16-k0,
+ * itself for k0 = 0).
  *   own[k0]  = |X_k|^2      , k = k1 + 16*k0      (k0 = 0..7  -> k in 0..127)
  *   mir[k0]  = |X_(256-k)|^2                       (-> 129..256)
  *   mid      = |X_128|^2 (meaningful in lane 0 only)
  * tw512: W512^k = exp(-2 pi i k/512), k = 0..255.
  */
+/* one pair: Z_k = (zr, zi), partner Z_(256-k) = (pr, pi), w = W512^k */
+template <typename T>
+BL_HD void bl_fft512_power1(T zr, T zi, T pr, T pi, bl_c2<T> w, T &own, T &mir) {
+  const T er = zr + pr, ei = zi - pi;
+  const T orr = zi + pi, oi = pr - zr;
+  const T q = oi * w.im, s = oi * w.re;
+  const T tr = bl_fma(orr, w.re, -q);
+  const T ti = bl_fma(orr, w.im, s);
+  const T ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
+  own = (T)0.25 * bl_fma(ar, ar, ai * ai);
+  mir = (T)0.25 * bl_fma(br, br, bi * bi);
+}
+
+template <typename T>
+BL_HD void bl_fft512_power(int k1, const T (&re)[16], const T (&im)[16], const T (&pr)[8],
+                           const T (&pi)[8], const bl_c2<T> *tw512, T (&own)[8], T (&mir)[8],
+                           T &mid) {
+#pragma unroll
+  for (int k0 = 0; k0 < 8; ++k0)
+    bl_fft512_power1<T>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr[k0], pi[k0], tw512[k1 + 16 * k0],
+                        own[k0], mir[k0]);
+  const T mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
+  mid = bl_fma(mr, mr, mi * mi);
+}
+
+/* index into a partner half-row buffer [lane][8] for lane k1, pair k0 (k0 = 0..7);
+ * returns -1 when the partner is the lane's own Z[0] (k1 = 0, k0 = 0) */
+BL_HD int bl_partner_slot(int k1, int k0) {
+  if (k1 != 0) return ((16 - k1) & 15) * 8 + (7 - k0);
+  return k0 == 0 ? -1 : (8 - k0);
+}
+
+/*
+ * Phase C (per lane k1, after a barrier): partner fetch from a complex buffer + power.
+ */
 template <typename T>
 BL_HD void bl_fft512_phaseC(int k1, const T (&re)[16], const T (&im)[16], const bl_c2<T> *tw512,
                             const bl_c2<T> *par, T (&own)[8], T (&mir)[8], T &mid) {
-  const int pl = (16 - k1) & 15;
+  T pr[8], pi[8];
 #pragma unroll
   for (int k0 = 0; k0 < 8; ++k0) {
-    const T zr = re[bl_pos16(k0)], zi = im[bl_pos16(k0)];
-    T pr, pi;
-    if (k1 != 0) {
-      bl_c2<T> v = par[pl * 8 + (7 - k0)];
-      pr = v.re; pi = v.im;
-    } else if (k0 == 0) {
-      pr = zr; pi = zi;
-    } else {
-      bl_c2<T> v = par[0 * 8 + (8 - k0)];
-      pr = v.re; pi = v.im;
-    }
-    const bl_c2<T> w = tw512[k1 + 16 * k0];
-    const T er = zr + pr, ei = zi - pi;
-    const T orr = zi + pi, oi = pr - zr;
-    const T q = oi * w.im, s = oi * w.re;
-    const T tr = bl_fma(orr, w.re, -q);
-    const T ti = bl_fma(orr, w.im, s);
-    const T ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
-    own[k0] = (T)0.25 * bl_fma(ar, ar, ai * ai);
-    mir[k0] = (T)0.25 * bl_fma(br, br, bi * bi);
+    const int sl = bl_partner_slot(k1, k0);
+    if (sl < 0) { pr[k0] = re[bl_pos16(0)]; pi[k0] = im[bl_pos16(0)]; }
+    else { const bl_c2<T> v = par[sl]; pr[k0] = v.re; pi[k0] = v.im; }
   }
-  const T mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
-  mid = bl_fma(mr, mr, mi * mi);
+  bl_fft512_power<T>(k1, re, im, pr, pi, tw512, own, mir, mid);
+}
+
+/* pass 1 in registers: 16-point DFT over m1 and the W256^(n0*k1) twiddles; the value
+ * for k1 stays at position bl_pos16(k1) */
+template <typename T>
+BL_HD void bl_fft512_pass1(int n0, T (&re)[16], T (&im)[16], const bl_c2<T> *tw256) {
+  bl_fft16(re, im);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) {
+    const int p = bl_pos16(k1);
+    const bl_c2<T> w = tw256[(n0 * k1) & 255];
+    T r = re[p], i = im[p];
+    bl_cmul(r, i, w.re, w.im);
+    if (n0 != 0) { re[p] = r; im[p] = i; }
+  }
 }
 
 #endif /* BL_FFT_H_ */

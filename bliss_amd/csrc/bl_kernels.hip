@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <vector>
@@ -615,12 +616,216 @@ __global__ __launch_bounds__(256) void k_env_windows(const int16_t *__restrict__
 }
 
 /* ------------------------------------------------------------------------- */
+/* k_env_windows2: same arithmetic, wave-autonomous pipeline                  */
+/*
+ * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, so the
+ * ~200 VGPRs the unrolled FIR/DFT code wants fit without spilling), no workgroup barrier
+ * inside the loop.  A compute wave owns 4 consecutive windows per round (one per
+ * 16-lane group) and does everything for them out of its private 11.4 KB LDS slice:
+ * normalise 1280 samples once, 17-tap FIR (20 outputs per lane from 36 register-held
+ * inputs, written back in place), the four 512-point f64 DFTs with split re/im
+ * exchanges, and the 4 x 257 power terms.  The f32-rounded, strictly ordered sum of
+ * ref tempo_atk_sort.c:142-149 is a 771-deep dependent chain per window: it runs on
+ * the eighth wave, one lane per window for the 28 windows of the tile, concurrently
+ * with the next round of the compute waves (terms buffer handed over through two LDS
+ * sequence words; waves of one workgroup are always co-resident, so the spin waits
+ * cannot deadlock).
+ */
+#define EV2_CWAVES 7
+#define EV2_TILE (4 * EV2_CWAVES)            /* windows per tile */
+#define EV2_SLOTS 1424                       /* 17 + 1280 samples + 63 pads, + 4 x 16 window heads */
+#define EV2_HEADS 1360
+#define EV2_TERMS_OFF (EV2_CWAVES * EV2_SLOTS * 8)
+#define EV2_TW_OFF (EV2_TERMS_OFF + EV2_TILE * 257 * 8)
+#define EV2_FLAG_OFF (EV2_TW_OFF + 2 * 256 * 16)
+#define EV2_LDS_BYTES (EV2_FLAG_OFF + 64)
+
+/* LDS slot of tile-local sample j of a compute wave: one pad after every 20 samples
+ * makes the per-lane stride 21 doubles (42 banks) -> conflict-free b64 accesses */
+__device__ __forceinline__ int ev2_slot(int j) { return 17 + j + ((j * 3277) >> 16); }
+
+__device__ __forceinline__ void ev2_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
+    const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
+    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *terms = reinterpret_cast<double *>(smem + EV2_TERMS_OFF); /* [EV2_TILE][257] */
+  c2d *tw256 = reinterpret_cast<c2d *>(smem + EV2_TW_OFF);
+  c2d *tw512 = tw256 + 256;
+  volatile int *flags = reinterpret_cast<volatile int *>(smem + EV2_FLAG_OFF);
+  /* flags[0..6]: last tile sequence whose terms compute wave c has published;
+   * flags[8]: last tile sequence the summing wave has consumed */
+
+  const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63, g = ln >> 4, l = ln & 15;
+  const bl_dsong sg = songs[blockIdx.y];
+  const bl_dstats st = stats[blockIdx.y];
+  const int16_t *p = pcm + sg.pcm_off;
+  if (tid < 256) { tw256[tid] = tb.tw256_d[tid]; tw512[tid] = tb.tw512_d[tid]; }
+  if (tid < 16) flags[tid] = 0;
+  __syncthreads();
+
+  const int n_tiles = (sg.n_windows + EV2_TILE - 1) / EV2_TILE;
+  const int n_used = 256 * (sg.n_windows + 1);
+  int seq = 0;
+
+  if (wave == EV2_CWAVES) {
+    /* ---- summing wave ---- */
+    __builtin_amdgcn_s_setprio(2);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      ++seq;
+      for (;;) {
+        const int f = ln < EV2_CWAVES ? flags[ln] : seq;
+        if (__all(f >= seq)) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int w = tile * EV2_TILE + ln;
+      if (ln < EV2_TILE && w < sg.n_windows && !(dbg & 1)) {
+        /* ref :142-151: float sum_fft += (double)|X_k|^2 for k = 0..256 in order */
+        const double *tg = terms + ln * 257;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int k = 0; k <= 256; ++k) sum = (float)((double)sum + tg[k]);
+        energies[sg.env_off + w] = sum;
+        lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (ln == 0) flags[8] = seq;
+    }
+    return;
+  }
+
+  /* ---- compute waves ---- */
+  double *buf = reinterpret_cast<double *>(smem) + wave * EV2_SLOTS;
+  const int mean = st.mean;
+  const double vprime = st.vprime, rcp = st.rcp;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    ++seq;
+    const int w0 = tile * EV2_TILE + 4 * wave; /* first of this wave's 4 windows */
+    const int s0 = w0 * 256;
+    if (dbg & 2) { /* measurement aid: hand-off only */
+      while (flags[8] < seq - 1) __builtin_amdgcn_s_sleep(1);
+      if (ln == 0) flags[wave] = seq;
+      continue;
+    }
+    ev2_wave_sync(); /* previous round's LDS reads are complete */
+    /* 1. 1280 samples -> normalised f64 (ref :109-114), 8 per 16-byte load */
+    for (int c = ln; c < 160; c += 64) {
+      const int i0 = s0 + 8 * c;
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (i0 + 8 <= n_used) q = *reinterpret_cast<const uint4 *>(p + i0);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
+        buf[ev2_slot(8 * c + 2 * k)] = bl_norm(lo - mean, vprime, rcp);
+        buf[ev2_slot(8 * c + 2 * k + 1)] = bl_norm(hi - mean, vprime, rcp);
+      }
+    }
+    ev2_wave_sync();
+    /* 2. FIR (ref :123-138).  Lane ln produces tile-local outputs 20*ln .. 20*ln+19 from
+     *    samples 20*ln-16 .. 20*ln+19: slots 21*ln .. 21*ln+15 and 21*ln+17 .. 21*ln+36 */
+    double yv[20], yh;
+    {
+      double r[36];
+      const double *ra = buf + 21 * ln;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = ra[i];
+#pragma unroll
+      for (int i = 0; i < 20; ++i) r[16 + i] = ra[17 + i];
+#pragma unroll
+      for (int i = 0; i < 20; ++i) {
+#define XR(m) r[i + 16 - (m)]
+        yv[i] = BL_FIR(XR);
+#undef XR
+      }
+      /* first 16 outputs of each window start from a zeroed delay line (ref :121):
+       * lane (g, l) filters sample l of window g with the taps that exist */
+#define XH(m) ((l - (m)) >= 0 ? buf[ev2_slot(256 * g + l - (m))] : 0.0)
+      yh = BL_FIR(XH);
+#undef XH
+    }
+    ev2_wave_sync(); /* every lane has read its inputs: outputs may overwrite them */
+#pragma unroll
+    for (int i = 0; i < 20; ++i) buf[21 * ln + 17 + i] = yv[i];
+    /* sample 256*(g+1)+q (q < 16) is both the tail of window g (steady state, above) and
+     * the head of window g+1 (zero state): heads live in their own 4 x 16 area */
+    buf[EV2_HEADS + ln] = yh;
+    ev2_wave_sync();
+    /* 3. DFT input of window g: lane l holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
+    double re[16], im[16];
+#pragma unroll
+    for (int m1 = 0; m1 < 16; ++m1) {
+      int s = ev2_slot(256 * g + 32 * m1 + 2 * l);
+      if (m1 == 0 && l < 8) s = EV2_HEADS + 16 * g + 2 * l;
+      re[m1] = buf[s];
+      im[m1] = buf[s + 1];
+    }
+    ev2_wave_sync(); /* window data is in registers; the slice becomes exchange space */
+    bl_fft512_pass1<double>(l, re, im, tw256);
+    double *xg = buf + g * 272; /* [16][17] doubles, re then im */
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + l] = re[bl_pos16(k1)];
+    ev2_wave_sync();
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) re[n0] = xg[l * 17 + n0];
+    ev2_wave_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + l] = im[bl_pos16(k1)];
+    ev2_wave_sync();
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) im[n0] = xg[l * 17 + n0];
+    ev2_wave_sync();
+    bl_fft16(re, im);
+    /* partner half rows (k0 = 8..15), row stride 9 doubles: re block then im block */
+    double *pgr = buf + g * 144, *pgi = buf + 576 + g * 144;
+#pragma unroll
+    for (int k0 = 8; k0 < 16; ++k0) {
+      pgr[l * 9 + (k0 - 8)] = re[bl_pos16(k0)];
+      pgi[l * 9 + (k0 - 8)] = im[bl_pos16(k0)];
+    }
+    ev2_wave_sync();
+    /* 4. the 4 x 257 power terms go straight to the summing wave's buffer once it has
+     *    drained the previous tile */
+    while (flags[8] < seq - 1) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double *tg = terms + (4 * wave + g) * 257;
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+      const int sl = bl_partner_slot(l, k0);
+      const int ps = (sl >> 3) * 9 + (sl & 7);
+      const double pr = sl < 0 ? re[bl_pos16(0)] : pgr[ps];
+      const double pi = sl < 0 ? im[bl_pos16(0)] : pgi[ps];
+      double own, mir;
+      bl_fft512_power1<double>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0], own,
+                               mir);
+      tg[l + 16 * k0] = own;
+      tg[256 - l - 16 * k0] = mir;
+    }
+    if (l == 0) {
+      const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
+      tg[128] = __builtin_fma(mr, mr, mi * mi);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ev2_wave_sync();
+    if (ln == 0) flags[wave] = seq;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* k_env_tail: one lane per song, 64 songs per wave                           */
+
+#define BL_TAIL_TW 57 /* windows per staged tile: 114 steps = 3 register-ring chunks of 38 */
 
 __global__ __launch_bounds__(64) void k_env_tail(const bl_dsong *__restrict__ songs,
                                                  const double *__restrict__ lc, int n_songs,
                                                  bl_amd_song_result *res, int what) {
-  __shared__ double tile[64 * 65];
+  __shared__ double tile[64 * (BL_TAIL_TW + 1)];
   __shared__ double rings[48 * 64];
   const int lane = threadIdx.x;
   const int song = blockIdx.x * 64 + lane;
@@ -629,30 +834,56 @@ __global__ __launch_bounds__(64) void k_env_tail(const bl_dsong *__restrict__ so
   if (valid) sg = songs[song];
   else { sg.nb_frames = 0; sg.n_windows = 0; sg.env_off = 0; sg.n = 1; sg.duration = 1; }
   const int N = 2 * sg.nb_frames;
-  int maxN = N;
+  int maxN = N, minN = valid ? N : 0x7fffffff;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
+  for (int off = 32; off > 0; off >>= 1) {
+    maxN = max(maxN, __shfl_xor(maxN, off));
+    minN = min(minN, __shfl_xor(minN, off));
+  }
   bl_tail t;
   t.init(sg.nb_frames, rings + lane, 64);
+  const double *mine = tile + lane * (BL_TAIL_TW + 1);
 
-  for (int j0 = 0; j0 < maxN; j0 += 128) {
-    /* stage 64 windows x 64 songs of the compressed envelope, transposed */
+  for (int j0 = 0; j0 < maxN; j0 += 2 * BL_TAIL_TW) {
+    /* stage BL_TAIL_TW windows x 64 songs of the compressed envelope, transposed;
+     * 16 independent loads in flight per lane */
     const int wbase = j0 >> 1;
-    for (int s = 0; s < 64; ++s) {
-      const int nw = __shfl(sg.n_windows, s);
-      const long long off = __shfl(sg.env_off, s);
-      const int w = wbase + lane;
-      tile[s * 65 + lane] = (w < nw) ? lc[off + w] : 0.0;
+    for (int sb = 0; sb < 64; sb += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int nw = __shfl(sg.n_windows, sb + u);
+        const long long off = __shfl(sg.env_off, sb + u);
+        const int w = wbase + lane;
+        v[u] = (lane < BL_TAIL_TW && w < nw) ? lc[off + w] : 0.0;
+      }
+      if (lane < BL_TAIL_TW) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tile[(sb + u) * (BL_TAIL_TW + 1) + lane] = v[u];
+      }
     }
     __syncthreads();
-    const int jend = min(128, maxN - j0);
-    for (int jj = 0; jj < jend; ++jj) {
+    const int jend = min(2 * BL_TAIL_TW, maxN - j0);
+    int jj = 0;
+    while (jj < jend) {
       const int j = j0 + jj;
+      /* wave-uniform: every song of the wave is in its steady state for the span */
+      if (jj + 38 <= jend && bl_tail::chunk_ok(j, minN)) {
+        t.fast_chunk38(mine + (jj >> 1), 1);
+        jj += 38;
+        continue;
+      }
+      if (jj + 1 < jend && bl_tail::fast_ok(j, minN)) {
+        t.fast_pair(mine[jj >> 1]);
+        jj += 2;
+        continue;
+      }
       if (j < N) {
-        const double x = (jj & 1) ? 0.0 : tile[lane * 65 + (jj >> 1)];
+        const double x = (jj & 1) ? 0.0 : mine[jj >> 1];
         t.step(j, x);
         if (j == N - 1) t.finish();
       }
+      ++jj;
     }
     __syncthreads();
   }
@@ -789,6 +1020,9 @@ struct Buf {
 struct Ctx {
   std::mutex mu;
   bool ready = false;
+  bool env_v1 = false;
+  int env_dbg = 0;
+  long long last_env_total = 0;
   int device = 0;
   int n_cu = 256;
   bl_tables tb{};
@@ -867,6 +1101,14 @@ int init_locked(int device) {
   g.tb.log101 = log((double)(1 + 100.0f)); /* ref tempo_atk_sort.c:188, log(1 + mu) */
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_ENV_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
+  {
+    const char *v = getenv("BL_AMD_ENV_V1"); /* A/B switch for measurements only */
+    g.env_v1 = v && v[0] == '1';
+    const char *d = getenv("BL_AMD_ENV_DBG"); /* bit 0: skip the ordered sums, bit 1: skip compute */
+    g.env_dbg = d ? atoi(d) : 0;
+  }
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   g.device = device;
@@ -972,6 +1214,7 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   if (ensure(g.energies, sizeof(float) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.lc, sizeof(double) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
 
+  g.last_env_total = env_total;
   bl_dsong *d_songs = static_cast<bl_dsong *>(g.songs.p);
   bl_dstats *d_stats = static_cast<bl_dstats *>(g.stats.p);
   unsigned *d_hist = static_cast<unsigned *>(g.hist.p);
@@ -1015,8 +1258,16 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   if (what & 4) {
     {
       ProfScope ps(PK_ENV, stream);
-      hipLaunchKernelGGL(k_env_windows, dim3(gx_env, n_songs), dim3(256), BL_ENV_LDS_BYTES, stream,
-                         d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc);
+      if (g.env_v1) {
+        hipLaunchKernelGGL(k_env_windows, dim3(gx_env, n_songs), dim3(256), BL_ENV_LDS_BYTES, stream,
+                           d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc);
+      } else {
+        /* one 512-thread workgroup per CU; blocks of a song split its 28-window tiles */
+        const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2);
+        hipLaunchKernelGGL(k_env_windows2, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                           EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc,
+                           g.env_dbg);
+      }
     }
     ProfScope ps(PK_TAIL, stream);
     hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(64), 0, stream, d_songs, d_lc, n_songs, d_results,
@@ -1338,6 +1589,18 @@ int bld_pair_host(const struct force_vector_s *a, const struct force_vector_s *b
                      static_cast<float *>(g.misc.p));
   BL_HIP_CHECK(hipMemcpy(out, g.misc.p, sizeof(float), hipMemcpyDeviceToHost));
   return BL_OK;
+}
+
+/* diagnostic: the per-window energies (ref tempo_atk_sort.c:150, filtered_array) of the
+ * most recent batch, songs concatenated, nb_frames slots per song (last two are unused) */
+long long bl_amd_last_energies(float *h_out, long long max_elems) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.ready || !g.energies.p || g.last_env_total <= 0) return 0;
+  const long long n = g.last_env_total < max_elems ? g.last_env_total : max_elems;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(h_out, g.energies.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return n;
 }
 
 void bl_amd_shutdown(void) {

@@ -46,12 +46,29 @@
 #define BL_BUT_A5 (-1.78845)
 #define BL_BUT_A6 0.24136
 
+/*
+ * x / c for a small integer constant c, bit-identical to the IEEE division the
+ * reference performs (out[k] /= smooth_width, ... / 10): q0 = x * RN(1/c) is within
+ * 2 ulp, the remainder fma is exact and one correction step lands on the correctly
+ * rounded quotient (x/c is never within 2^-100 of a rounding boundary unless it is
+ * exactly representable).  Three multiply-class instructions instead of the ~30 of a
+ * software f64 division — this sits on the per-step critical path of the tail.
+ * Checked against `/` on the CPU by tests/host/test_tail_host.cpp.
+ */
+BL_THD double bl_div_const(double x, double c, double rc) {
+  const double q0 = x * rc;
+  const double r0 = __builtin_fma(-q0, c, x);
+  return __builtin_fma(r0, rc, q0);
+}
+#define BL_DIV19(x) bl_div_const((x), 19.0, 1.0 / 19.0)
+#define BL_DIV10(x) bl_div_const((x), 10.0, 1.0 / 10.0)
+
 /* peak detector over the twice-smoothed signal (ref :275-280) */
 struct bl_peaks {
   double p1, p2; /* out2[i-1], out2[i-2] */
-  int beat;
-  BL_THD void init() { p1 = 0; p2 = 0; beat = 0; }
-  BL_THD void push(int i, double v) {
+  int beat, i;   /* i: index of the next value */
+  BL_THD void init() { p1 = 0; p2 = 0; beat = 0; i = 0; }
+  BL_THD void push(double v) {
     if (i >= 2) {
       const float epsilon = 0.000001f;
       double dl = p1 - p2, dr = p1 - v;
@@ -59,13 +76,14 @@ struct bl_peaks {
     }
     p2 = p1;
     p1 = v;
+    ++i;
   }
 };
 
 /*
  * One bl_rectangular_filter(out, in, N, 19) as a stream.  push(i, in_i, old_i)
  * must be called for i = 0..N-1 in order, then finish(); old_i is the previous
- * content of out[i].  Outputs are handed to `sink.push(i, out_i)` in order:
+ * content of out[i].  Outputs are handed to `sink.push(out_i)` in index order:
  *   i <= 8          at push(i)       : old_i / 19
  *   9 <= i <= N-11  at push(i + 9)   : R_(i-9) / 19, R_0 = in_0+..+in_18,
  *                                      R_k = (R_(k-1) - in_(k-1)) + in_(k+18)
@@ -76,26 +94,27 @@ struct bl_peaks {
  */
 template <bool KEEP_OLD> struct bl_box19 {
   double run;
-  int N;
-  BL_THD void init(int n) { run = 0; N = n; }
+  int N, t, s19, s10; /* next input index and its ring slots (t % 19, t % 10) */
+  BL_THD void init(int n) { run = 0; N = n; t = 0; s19 = 0; s10 = 0; }
 
   template <typename SINK>
-  BL_THD void push(int t, double v, double old, double *ring, double *olds, int stride,
-                   SINK &sink) {
-    const int slot = t % BL_BOX;
+  BL_THD void push(double v, double old, double *ring, double *olds, int stride, SINK &sink) {
     if (t < BL_BOX) {
       run += v; /* ref :25-26 */
     } else {
-      run -= ring[slot * stride]; /* in[t-19], ref :30 */
-      run += v;                   /* ref :31 */
+      run -= ring[s19 * stride]; /* in[t-19], ref :30 */
+      run += v;                  /* ref :31 */
     }
-    ring[slot * stride] = v;
-    if (KEEP_OLD) olds[(t % 10) * stride] = old;
+    ring[s19 * stride] = v;
+    if (KEEP_OLD) olds[s10 * stride] = old;
     if (t <= 8) {
-      sink.push(t, old / BL_BOX);
+      sink.push(BL_DIV19(old));
     } else if (t >= BL_BOX - 1 && t <= N - 2) {
-      sink.push(t - 9, run / BL_BOX); /* out[k + half - 1] = tempsum, k = t-18 */
+      sink.push(BL_DIV19(run)); /* out[k + half - 1] = tempsum, k = t-18 */
     }
+    ++t;
+    s19 = s19 == BL_BOX - 1 ? 0 : s19 + 1;
+    s10 = s10 == 9 ? 0 : s10 + 1;
   }
 
   template <typename SINK>
@@ -103,10 +122,10 @@ template <bool KEEP_OLD> struct bl_box19 {
     /* out[N - half] += in[k], k = N-19 .. N-1 (ref :34-35) */
     double acc = KEEP_OLD ? olds[((N - 10) % 10) * stride] : 0.0;
     for (int k = N - BL_BOX; k < N; ++k) acc += ring[(k % BL_BOX) * stride];
-    sink.push(N - BL_BOX_HALF, acc / BL_BOX);
+    sink.push(BL_DIV19(acc));
     for (int i = N - 9; i < N; ++i) {
       double old = KEEP_OLD ? olds[(i % 10) * stride] : 0.0;
-      sink.push(i, old / BL_BOX);
+      sink.push(BL_DIV19(old));
     }
   }
 };
@@ -117,7 +136,7 @@ struct bl_tail_stage2 {
   bl_peaks peaks;
   double *ring;
   int stride;
-  BL_THD void push(int i, double v) { box.push(i, v, 0.0, ring, (double *)0, stride, peaks); }
+  BL_THD void push(double v) { box.push(v, 0.0, ring, (double *)0, stride, peaks); }
 };
 
 struct bl_tail {
@@ -168,12 +187,172 @@ struct bl_tail {
     if (j == 0) dj = y;
     else { dj = y - y1; dj = dj > 0 ? dj : 0; }
     const float lambda = 0.8f; /* ref :171 */
-    const double wa = (1 - lambda) * y + lambda * 172 * dj / 10; /* ref :230-231 */
+    const double wa = (1 - lambda) * y + BL_DIV10(lambda * 172 * dj); /* ref :230-231 */
     x6 = x5; x5 = x4; x4 = x3; x3 = x2; x2 = x1; x1 = x;
     y6 = y5; y5 = y4; y4 = y3; y3 = y2; y2 = y1; y1 = y;
     double ss = 0; /* ref :259-263: smoothed_sum[N-1] stays 0 */
     if (j <= N - 2) { atk += wa; ss = wa; } /* ref :246-248 */
-    box1.push(j, ss, wa, ring1, olds1, stride, st2);
+    box1.push(ss, wa, ring1, olds1, stride, st2);
+  }
+
+  /* ---- steady-state fast path -------------------------------------------------
+   * For 40 <= j <= N - 12 every conditional of step() is decided (both box filters
+   * and the peak detector emit exactly one value per step), so two steps (even j with
+   * input x, odd j+1 with the stuffed zero) can run as straight-line code.  The
+   * feed-forward sum skips its `+= b[k] * 0.0` terms: every partial sum is a sum of
+   * products of positive taps with non-negative inputs, so adding +0.0 is the identity.
+   * Same values, same order, bit-identical to step() (tests/host/test_tail_host.cpp). */
+  BL_THD static bool fast_ok(int j, int n) { return (j & 1) == 0 && j >= 40 && j + 1 <= n - 12; }
+
+  BL_THD void fast_tail(double y, double wa) {
+    atk += wa;
+    double *r1 = ring1 + box1.s19 * stride;
+    box1.run -= *r1;
+    box1.run += wa;
+    *r1 = wa;
+    olds1[box1.s10 * stride] = wa;
+    const double o1 = BL_DIV19(box1.run);
+    ++box1.t;
+    box1.s19 = box1.s19 == BL_BOX - 1 ? 0 : box1.s19 + 1;
+    box1.s10 = box1.s10 == 9 ? 0 : box1.s10 + 1;
+    double *r2 = st2.ring + st2.box.s19 * stride;
+    st2.box.run -= *r2;
+    st2.box.run += o1;
+    *r2 = o1;
+    const double o2 = BL_DIV19(st2.box.run);
+    ++st2.box.t;
+    st2.box.s19 = st2.box.s19 == BL_BOX - 1 ? 0 : st2.box.s19 + 1;
+    st2.box.s10 = st2.box.s10 == 9 ? 0 : st2.box.s10 + 1;
+    const float epsilon = 0.000001f;
+    const double dl = st2.peaks.p1 - st2.peaks.p2, dr = st2.peaks.p1 - o2;
+    st2.peaks.beat += (dl > epsilon && dr > epsilon) ? 1 : 0;
+    st2.peaks.p2 = st2.peaks.p1;
+    st2.peaks.p1 = o2;
+    ++st2.peaks.i;
+    (void)y;
+  }
+
+  BL_THD double fast_feedback(double d) {
+    double c = 0;
+    c += BL_BUT_A1 * y1;
+    c += BL_BUT_A2 * y2;
+    c += BL_BUT_A3 * y3;
+    c += BL_BUT_A4 * y4;
+    c += BL_BUT_A5 * y5;
+    c += BL_BUT_A6 * y6;
+    const double y = (d - c) / BL_BUT_A0;
+    double dj = y - y1;
+    dj = dj > 0 ? dj : 0;
+    const float lambda = 0.8f;
+    const double wa = (1 - lambda) * y + BL_DIV10(lambda * 172 * dj);
+    y6 = y5; y5 = y4; y4 = y3; y3 = y2; y2 = y1; y1 = y;
+    fast_tail(y, wa);
+    return y;
+  }
+
+  /* one steady step with the two box-filter rings held in registers: ra / rb are the
+   * 19 most recent inputs of box 1 / box 2 in ring order, P the (static) ring slot */
+  template <int P> BL_THD void reg_step(double d, double (&ra)[BL_BOX], double (&rb)[BL_BOX]) {
+    double c = 0;
+    c += BL_BUT_A1 * y1;
+    c += BL_BUT_A2 * y2;
+    c += BL_BUT_A3 * y3;
+    c += BL_BUT_A4 * y4;
+    c += BL_BUT_A5 * y5;
+    c += BL_BUT_A6 * y6;
+    const double y = (d - c) / BL_BUT_A0;
+    double dj = y - y1;
+    dj = dj > 0 ? dj : 0;
+    const float lambda = 0.8f;
+    const double wa = (1 - lambda) * y + BL_DIV10(lambda * 172 * dj);
+    y6 = y5; y5 = y4; y4 = y3; y3 = y2; y2 = y1; y1 = y;
+    atk += wa;
+    box1.run -= ra[P];
+    box1.run += wa;
+    ra[P] = wa;
+    const double o1 = BL_DIV19(box1.run);
+    st2.box.run -= rb[P];
+    st2.box.run += o1;
+    rb[P] = o1;
+    const double o2 = BL_DIV19(st2.box.run);
+    const float epsilon = 0.000001f;
+    const double dl = st2.peaks.p1 - st2.peaks.p2, dr = st2.peaks.p1 - o2;
+    st2.peaks.beat += (dl > epsilon && dr > epsilon) ? 1 : 0;
+    st2.peaks.p2 = st2.peaks.p1;
+    st2.peaks.p1 = o2;
+  }
+
+  template <int Q> BL_THD void reg_pairs(const double *xin, int xstride, double (&ra)[BL_BOX],
+                                         double (&rb)[BL_BOX]) {
+    if constexpr (Q < BL_BOX) {
+      const double x = xin[Q * xstride];
+      double d = BL_BUT_B0 * x;
+      d += BL_BUT_B2 * x2;
+      d += BL_BUT_B2 * x4;
+      d += BL_BUT_B0 * x6;
+      reg_step<(2 * Q) % BL_BOX>(d, ra, rb);
+      double e = BL_BUT_B1 * x;
+      e += BL_BUT_B3 * x2;
+      e += BL_BUT_B1 * x4;
+      reg_step<(2 * Q + 1) % BL_BOX>(e, ra, rb);
+      x6 = x4; x4 = x2; x2 = x;
+      reg_pairs<Q + 1>(xin, xstride, ra, rb);
+    }
+  }
+
+  /* 38 steady steps (19 even inputs xin[q * xstride]) starting at even j; requires
+   * fast_ok(j, N) and fast_ok(j + 36, N).  38 = 2 * 19 steps are two full turns of both
+   * rings, so the rings come back to LDS in the slots they left and no counter other
+   * than t / s10 moves.  Box 2 lags box 1 by 9 inputs and the peak detector by 18, but
+   * all three see exactly one value per step. */
+  BL_THD static bool chunk_ok(int j, int n) { return fast_ok(j, n) && fast_ok(j + 36, n); }
+
+  BL_THD void fast_chunk38(const double *xin, int xstride) {
+    double ra[BL_BOX], rb[BL_BOX];
+    {
+      int sa = box1.s19, sb = st2.box.s19;
+#pragma unroll
+      for (int k = 0; k < BL_BOX; ++k) {
+        ra[k] = ring1[sa * stride];
+        rb[k] = st2.ring[sb * stride];
+        sa = sa == BL_BOX - 1 ? 0 : sa + 1;
+        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
+      }
+    }
+    reg_pairs<0>(xin, xstride, ra, rb);
+    {
+      int sa = box1.s19, sb = st2.box.s19;
+#pragma unroll
+      for (int k = 0; k < BL_BOX; ++k) {
+        ring1[sa * stride] = ra[k];
+        st2.ring[sb * stride] = rb[k];
+        sa = sa == BL_BOX - 1 ? 0 : sa + 1;
+        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
+      }
+    }
+    box1.t += 38;
+    st2.box.t += 38;
+    st2.peaks.i += 38;
+    /* the skipped olds1 stores are all overwritten before finish() reads them: at least
+     * 11 generic steps follow any chunk (fast_ok), olds1 holds 10 */
+    box1.s10 = (box1.s10 + 8) % 10;
+    st2.box.s10 = (st2.box.s10 + 8) % 10;
+  }
+
+  /* steps j (even, input x) and j+1 (odd, zero); requires fast_ok(j, N) */
+  BL_THD void fast_pair(double x) {
+    /* even: x2, x4, x6 are the previous even inputs; x1, x3, x5 are stuffed zeros */
+    double d = BL_BUT_B0 * x;
+    d += BL_BUT_B2 * x2;
+    d += BL_BUT_B2 * x4;
+    d += BL_BUT_B0 * x6;
+    fast_feedback(d);
+    /* odd: the inputs one, three and five steps back are x, x2, x4 */
+    double e = BL_BUT_B1 * x;
+    e += BL_BUT_B3 * x2;
+    e += BL_BUT_B1 * x4;
+    fast_feedback(e);
+    x6 = x4; x4 = x2; x2 = x; /* x1, x3, x5 stay 0 */
   }
 
   BL_THD void finish() {

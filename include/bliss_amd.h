@@ -98,6 +98,12 @@ void bl_amd_profile(int enable);
 void bl_amd_profile_reset(void);
 double bl_amd_profile_ms(const char *name, int *launches);
 
+/* Diagnostic: per-window envelope energies (the reference's filtered_array,
+ * ref src/tempo_atk_sort.c:150) of the most recent batch, songs concatenated with
+ * nb_frames slots each (the last two of a song are never written).  Copies up to
+ * max_elems floats to h_out; returns the number copied, 0 if none, -1 on error. */
+long long bl_amd_last_energies(float *h_out, long long max_elems);
+
 /* Releases the workspace, streams and pinned staging buffers. */
 void bl_amd_shutdown(void);
 

@@ -9,7 +9,7 @@
 #include "../../bliss_amd/csrc/bl_tail.h"
 #include "../../oracle/bliss_oracle.h"
 
-static int check(unsigned seed, unsigned rate, unsigned ch, unsigned secs, unsigned extra) {
+static int check(unsigned seed, unsigned rate, unsigned ch, unsigned secs, unsigned extra, bool use_fast = true) {
   unsigned n = rate * ch * secs + extra;
   std::vector<int16_t> pcm(n);
   orc_synth_fill(pcm.data(), n, seed, rate, ch);
@@ -21,10 +21,19 @@ static int check(unsigned seed, unsigned rate, unsigned ch, unsigned secs, unsig
   bl_tail t;
   t.init(r.nb_frames, scratch.data(), 1);
   const double log101 = log((double)(1 + 100.0f)); // C semantics: log() of a double
-  for (int j = 0; j < 2 * r.nb_frames; ++j) {
+  const int N = 2 * r.nb_frames;
+  int fast_pairs = 0;
+  for (int j = 0; j < N;) {
     double x = 0;
     if ((j & 1) == 0) x = bl_tail_compress((double)en[j / 2], log101);
-    t.step(j, x);
+    if (use_fast && (seed & 1) == 0 && bl_tail::chunk_ok(j, N)) {  // even seeds: register-ring chunks
+      double xs[19];
+      for (int q = 0; q < 19; ++q) xs[q] = bl_tail_compress((double)en[j / 2 + q], log101);
+      t.fast_chunk38(xs, 1);
+      j += 38;
+      fast_pairs += 19;
+    } else if (use_fast && bl_tail::fast_ok(j, N)) { t.fast_pair(x); j += 2; ++fast_pairs; }
+    else { t.step(j, x); ++j; }
   }
   t.finish();
   float tempo = bl_tail_tempo(t.beat(), secs), attack = bl_tail_attack(t.atk, (int)n);
@@ -34,14 +43,34 @@ static int check(unsigned seed, unsigned rate, unsigned ch, unsigned secs, unsig
   return ok;
 }
 
+// bl_div_const must agree with IEEE division bit for bit
+static int check_div() {
+  unsigned long long st = 88172645463325252ull;
+  int bad = 0;
+  for (int i = 0; i < 20000000; ++i) {
+    st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+    double x = (double)(st >> 11) * (1.0 / 9007199254740992.0);   // [0,1)
+    int e = (int)((st >> 3) % 80) - 60;
+    x = ldexp(x, e);
+    if (st & 1) x = -x;
+    volatile double a = x / 19.0, b = x / 10.0;
+    if (BL_DIV19(x) != a || BL_DIV10(x) != b) ++bad;
+  }
+  printf("bl_div_const vs IEEE '/': %d mismatches in 2e7 samples\n", bad);
+  return bad == 0;
+}
+
 int main() {
-  int ok = 1;
+  int ok = check_div();
   ok &= check(1, 22050, 2, 11, 0);
   ok &= check(2, 44100, 2, 30, 0);
   ok &= check(3, 44100, 1, 20, 777);
   ok &= check(4, 8000, 1, 1, 0);      // 8000 samples -> N = 30: short-array edges
   ok &= check(5, 5120, 1, 1, 0);      // N = 20: the minimum the reference supports
   ok &= check(6, 5632, 1, 1, 0);      // N = 22
+  ok &= check(7, 22050, 2, 7, 0, false);  // generic path only
+  ok &= check(8, 13312, 1, 1, 0);     // N = 52: exactly one fast pair
+  ok &= check(9, 14000, 1, 1, 0);     // N = 54
   puts(ok ? "OK" : "FAIL");
   return ok ? 0 : 1;
 }
