@@ -37,12 +37,6 @@ HBM_ACHIEVABLE_GBS = 6290.0             # measured float4 copy, same guide
 FP64_VALU_PEAK_TFLOPS = 78.6            # spec (FMA = 2 flop); the faithful path's real ceiling
 
 
-def shard_counts(total, world):
-    """songs per rank for a corpus of `total` songs (equal-length songs: contiguous blocks)."""
-    base, rem = divmod(total, world)
-    return [base + (1 if r < rem else 0) for r in range(world)]
-
-
 def cpu_baseline(seconds_budget=25.0):
     """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded
     sample of the same workload: one process per core (not threads: the reference is not
@@ -139,8 +133,10 @@ def main():
         t = torch.tensor([songs], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         songs = int(t.item())
+    from bliss_amd.dist import gather_force_vectors, shard_range
     total_songs = songs * world
-    my_first = rank * songs
+    my_first, my_count = shard_range(total_songs, rank, world)
+    assert my_count == songs
 
     corpus = bliss_amd.DeviceCorpus([song_samples] * songs, 2, args.seconds, device=f"cuda:{local_rank}")
     corpus.synth(seed_base=my_first, sample_rate=SAMPLE_RATE)
@@ -153,10 +149,7 @@ def main():
     def step():
         corpus.analyze()
         mine = corpus.force_vectors()
-        if world > 1:
-            dist.all_gather_into_tensor(all_vecs, mine)
-        else:
-            all_vecs.copy_(mine)
+        all_vecs.copy_(gather_force_vectors(mine, [songs] * world))   # RCCL all-gather, 16 B/song
         rc = lib.bl_amd_distance_matrix_device(C.c_void_p(all_vecs.data_ptr()), total_songs, my_first,
                                                songs, C.c_void_p(rows.data_ptr()), stream)
         assert rc == 0

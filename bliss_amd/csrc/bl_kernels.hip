@@ -704,29 +704,45 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   double *buf = reinterpret_cast<double *>(smem) + wave * EV2_SLOTS;
   const int mean = st.mean;
   const double vprime = st.vprime, rcp = st.rcp;
+  /* the wave's 1280 samples of a round are 160 16-byte chunks: lane ln owns chunks ln,
+   * ln + 64 and (ln < 32) ln + 128; they are fetched one round ahead so that the HBM
+   * latency hides behind the arithmetic of the current round */
+  uint4 pre[3];
+  auto fetch = [&](int tile_) {
+    const int base = (tile_ * EV2_TILE + 4 * wave) * 256;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = ln + 64 * u;
+      const int i0 = base + 8 * c;
+      pre[u] = make_uint4(0, 0, 0, 0);
+      if (c < 160 && tile_ < n_tiles && i0 + 8 <= n_used)
+        pre[u] = *reinterpret_cast<const uint4 *>(p + i0);
+    }
+  };
+  fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     ++seq;
-    const int w0 = tile * EV2_TILE + 4 * wave; /* first of this wave's 4 windows */
-    const int s0 = w0 * 256;
     if (dbg & 2) { /* measurement aid: hand-off only */
       while (flags[8] < seq - 1) __builtin_amdgcn_s_sleep(1);
       if (ln == 0) flags[wave] = seq;
       continue;
     }
     ev2_wave_sync(); /* previous round's LDS reads are complete */
-    /* 1. 1280 samples -> normalised f64 (ref :109-114), 8 per 16-byte load */
-    for (int c = ln; c < 160; c += 64) {
-      const int i0 = s0 + 8 * c;
-      uint4 q = make_uint4(0, 0, 0, 0);
-      if (i0 + 8 <= n_used) q = *reinterpret_cast<const uint4 *>(p + i0);
-      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+    /* 1. 1280 samples -> normalised f64 (ref :109-114), 8 per prefetched 16-byte chunk */
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-        buf[ev2_slot(8 * c + 2 * k)] = bl_norm(lo - mean, vprime, rcp);
-        buf[ev2_slot(8 * c + 2 * k + 1)] = bl_norm(hi - mean, vprime, rcp);
+    for (int u = 0; u < 3; ++u) {
+      const int c = ln + 64 * u;
+      if (c < 160) {
+        const unsigned w[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
+          buf[ev2_slot(8 * c + 2 * k)] = bl_norm(lo - mean, vprime, rcp);
+          buf[ev2_slot(8 * c + 2 * k + 1)] = bl_norm(hi - mean, vprime, rcp);
+        }
       }
     }
+    fetch(tile + gridDim.x); /* next round's samples */
     ev2_wave_sync();
     /* 2. FIR (ref :123-138).  Lane ln produces tile-local outputs 20*ln .. 20*ln+19 from
      *    samples 20*ln-16 .. 20*ln+19: slots 21*ln .. 21*ln+15 and 21*ln+17 .. 21*ln+36 */
