@@ -200,8 +200,21 @@ def main():
             # faithful-arithmetic count of the kernel: ~75 f64 VALU instructions per sample
             # (normalise 4, FIR 26, FFT+split 33, f32-ordered sum 3, log 0.1)
             f64_rate = 75.0 * song_samples * songs / (dom["ms_avg"] * 1e-3) / 1e12
-            roof = {"bound": "hbm", "kernel": "k_env_windows", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE from the committed separate-pass PMC
+            # profile (profiles/*_hbm_traffic.json, corrected as MI355X_MICROARCH.md prescribes),
+            # scaled from its per-song figure to this launch's song count; None if absent
+            traffic = None
+            try:
+                import glob
+                tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
+                traffic = tj["kernels"]["k_env_windows2"]["hbm_bytes_per_song"] * songs * \
+                    (song_samples / 15876000.0)
+            except Exception:
+                pass
+            roof = {"bound": "hbm", "kernel": "k_env_windows2", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                                      "profiles/*_hbm_traffic.json, scaled per song",
                     "frac_of_measured_copy_peak": ach / HBM_ACHIEVABLE_GBS,
                     "ms_avg_launch": dom["ms_avg"], "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": launch_bytes,
