@@ -325,17 +325,23 @@ struct bl_tables {
 
 #define BL_FREQ_CHUNK 256 /* frames per partial spectrum */
 #define BL_FREQ_LDS_BYTES                                                              \
-  (16 * BL_FFT_XCH_ELEMS * 8 + 16 * BL_FFT_PAR_ELEMS * 8 + 2 * 256 * 8 + 512 * 4)
+  (16 * BL_FFT_XCH_ELEMS * 8 + 16 * BL_FFT_PAR_ELEMS * 8 + 2 * 256 * 8 + 512 * 4 + BL_HIST_BINS * 4)
 
+/* SCAN = true fuses k_pcm_scan's statistics into the same pass over the PCM (the frames
+ * cover every sample except a tail shorter than one frame, which the block that owns the
+ * last chunk scans separately), so the analysis reads the PCM twice instead of three times. */
+template <bool SCAN>
 __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__ pcm,
                                                      const bl_dsong *__restrict__ songs,
-                                                     bl_tables tb, float *partial) {
+                                                     bl_tables tb, float *partial, bl_dstats *stats,
+                                                     unsigned *hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c2f *xch = reinterpret_cast<c2f *>(smem);                       /* 16 x 272 */
   c2f *par = xch + 16 * BL_FFT_XCH_ELEMS;                         /* 16 x 128 */
   c2f *tw256 = par + 16 * BL_FFT_PAR_ELEMS;
   c2f *tw512 = tw256 + 256;
   float *hann = reinterpret_cast<float *>(tw512 + 256);
+  unsigned *lh = reinterpret_cast<unsigned *>(hann + 512);        /* SCAN: 4096-bin histogram */
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
   const bl_dsong sg = songs[blockIdx.y];
   const int16_t *p = pcm + sg.pcm_off;
@@ -343,7 +349,13 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
   tw512[tid] = tb.tw512_f[tid];
   hann[tid] = tb.hann[tid];
   hann[tid + 256] = tb.hann[tid + 256];
+  if (SCAN)
+    for (int i = tid; i < BL_HIST_BINS; i += 256) lh[i] = 0;
   __syncthreads();
+  long long ssum = 0;
+  unsigned long long ssq = 0;
+  unsigned sfirst = 0xFFFFFFFFu;
+  int slast = -1;
 
   c2f *gx = xch + g * BL_FFT_XCH_ELEMS, *gp = par + g * BL_FFT_PAR_ELEMS;
   float *red = reinterpret_cast<float *>(smem); /* [16][256], aliases xch */
@@ -367,8 +379,17 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
         for (int m1 = 0; m1 < 16; ++m1) {
           const uint2 w = q[16 * m1 + l];
           const int d = 32 * m1 + 2 * l;
-          const int s0 = ((int)(short)(w.x & 0xFFFFu) + (int)(short)(w.x >> 16)) / 2;
-          const int s1 = ((int)(short)(w.y & 0xFFFFu) + (int)(short)(w.y >> 16)) / 2;
+          const int a0 = (int)(short)(w.x & 0xFFFFu), a1 = (int)(short)(w.x >> 16);
+          const int a2 = (int)(short)(w.y & 0xFFFFu), a3 = (int)(short)(w.y >> 16);
+          if (SCAN) {
+            const unsigned i0 = (unsigned)f * 1024u + 2u * (unsigned)d;
+            scan_sample(a0, i0, ssum, ssq, sfirst, slast, lh);
+            scan_sample(a1, i0 + 1u, ssum, ssq, sfirst, slast, lh);
+            scan_sample(a2, i0 + 2u, ssum, ssq, sfirst, slast, lh);
+            scan_sample(a3, i0 + 3u, ssum, ssq, sfirst, slast, lh);
+          }
+          const int s0 = (a0 + a1) / 2;
+          const int s1 = (a2 + a3) / 2;
           re[m1] = (float)s0 * hann[d];
           im[m1] = (float)s1 * hann[d + 1];
         }
@@ -378,8 +399,14 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
         for (int m1 = 0; m1 < 16; ++m1) {
           const unsigned w = q[16 * m1 + l];
           const int d = 32 * m1 + 2 * l;
-          re[m1] = (float)(int)(short)(w & 0xFFFFu) * hann[d];
-          im[m1] = (float)(int)(short)(w >> 16) * hann[d + 1];
+          const int a0 = (int)(short)(w & 0xFFFFu), a1 = (int)(short)(w >> 16);
+          if (SCAN) {
+            const unsigned i0 = (unsigned)f * 512u + (unsigned)d;
+            scan_sample(a0, i0, ssum, ssq, sfirst, slast, lh);
+            scan_sample(a1, i0 + 1u, ssum, ssq, sfirst, slast, lh);
+          }
+          re[m1] = (float)a0 * hann[d];
+          im[m1] = (float)a1 * hann[d + 1];
         }
       } else {
 #pragma unroll
@@ -411,6 +438,34 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
     for (int gg = 0; gg < 16; ++gg) acc += red[gg * 256 + tid];
     partial[((size_t)sg.part_off + chunk) * 256 + tid] = acc;
     __syncthreads();
+  }
+  if (SCAN) {
+    /* samples past the last whole frame (fewer than 512 * channels) */
+    if (blockIdx.x == 0) {
+      const unsigned covered = (unsigned)sg.n_frames * 512u * (unsigned)sg.channels;
+      for (unsigned i = covered + tid; i < (unsigned)sg.n; i += 256u)
+        scan_sample((int)p[i], i, ssum, ssq, sfirst, slast, lh);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ssum += __shfl_down(ssum, off);
+      ssq += __shfl_down(ssq, off);
+      sfirst = min(sfirst, (unsigned)__shfl_down((int)sfirst, off));
+      slast = max(slast, __shfl_down(slast, off));
+    }
+    bl_dstats *st = stats + blockIdx.y;
+    if ((tid & 63) == 0) {
+      atomicAdd(&st->sum, (unsigned long long)ssum);
+      atomicAdd(&st->sumsq, ssq);
+      atomicMin(&st->first, sfirst);
+      atomicMax(&st->last, slast);
+    }
+    __syncthreads();
+    unsigned *gh = hist + (size_t)blockIdx.y * BL_HIST_BINS;
+    for (int i = tid; i < BL_HIST_BINS; i += 256) {
+      const unsigned c = lh[i];
+      if (c) atomicAdd(&gh[i], c);
+    }
   }
 }
 
@@ -1038,6 +1093,7 @@ struct Ctx {
   bool ready = false;
   bool env_v1 = false;
   int env_dbg = 0;
+  bool fuse_scan = false;
   long long last_env_total = 0;
   int device = 0;
   int n_cu = 256;
@@ -1124,8 +1180,12 @@ int init_locked(int device) {
     g.env_v1 = v && v[0] == '1';
     const char *d = getenv("BL_AMD_ENV_DBG"); /* bit 0: skip the ordered sums, bit 1: skip compute */
     g.env_dbg = d ? atoi(d) : 0;
+    const char *f = getenv("BL_AMD_FUSE_SCAN");
+    g.fuse_scan = f && f[0] == '1';
   }
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   g.device = device;
   g.ready = true;
@@ -1245,7 +1305,16 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   BL_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
   const int tb64 = (n_songs + 63) / 64;
   hipLaunchKernelGGL(k_stats_init, dim3(tb64), dim3(64), 0, stream, d_stats, n_songs);
-  {
+  /* k_freq_frames<true> can gather the statistics in the same pass (2 PCM reads instead of
+   * 3), but measured 49 ms against 9.6 + 9.9 ms for the two separate passes (1 024 S180
+   * songs): the histogram's LDS atomics queue in front of every barrier of the DFT
+   * exchanges.  Kept selectable (BL_AMD_FUSE_SCAN=1) until the histogram is cheaper. */
+  const bool fused = (what & 2) != 0 && g.fuse_scan;
+  if (fused) {
+    ProfScope ps(PK_FREQ, stream);
+    hipLaunchKernelGGL(k_freq_frames<true>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES,
+                       stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
+  } else {
     ProfScope ps(PK_SCAN, stream);
     hipLaunchKernelGGL(k_pcm_scan, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm, d_songs,
                        d_stats, d_hist);
@@ -1262,10 +1331,10 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
                        d_results);
   }
   if (what & 2) {
-    {
+    if (!fused) {
       ProfScope ps(PK_FREQ, stream);
-      hipLaunchKernelGGL(k_freq_frames, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream,
-                         d_pcm, d_songs, g.tb, d_partial);
+      hipLaunchKernelGGL(k_freq_frames<false>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES,
+                         stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
     }
     ProfScope ps(PK_FREQ_FIN, stream);
     hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, d_songs,
