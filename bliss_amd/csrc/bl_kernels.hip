@@ -695,6 +695,16 @@ __global__ __launch_bounds__(256) void k_env_windows(const int16_t *__restrict__
 #define EV2_FLAG_OFF (EV2_TW_OFF + 2 * 256 * 16)
 #define EV2_LDS_BYTES (EV2_FLAG_OFF + 64)
 
+/* cross-lane move of a double through DPP (two 32-bit moves).  CTRL 0x138 = wave_shr:1
+ * (lane i reads lane i-1), 0x110+m = row_shr:m inside each 16-lane row; lanes without a
+ * source read 0 (bound_ctrl) */
+template <int CTRL> __device__ __forceinline__ double bl_dpp_f64(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b & 0xFFFFFFFFull), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 /* LDS slot of tile-local sample j of a compute wave: one pad after every 20 samples
  * makes the per-lane stride 21 doubles (42 banks) -> conflict-free b64 accesses */
 __device__ __forceinline__ int ev2_slot(int j) { return 17 + j + ((j * 3277) >> 16); }
@@ -727,31 +737,64 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   const int n_tiles = (sg.n_windows + EV2_TILE - 1) / EV2_TILE;
   const int n_used = 256 * (sg.n_windows + 1);
   int seq = 0;
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long ph_t = 0;
+#define EV2_MARK(i)                                                     \
+  if (dbg & 8) {                                                        \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();     \
+    ph[i] += now_ - ph_t;                                               \
+    ph_t = now_;                                                        \
+  }
+  const long long dbg_c0 = (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  const long long dbg_w0 = (dbg & 4) ? (long long)wall_clock64() : 0;
 
   if (wave == EV2_CWAVES) {
     /* ---- summing wave ---- */
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(3);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       ++seq;
+      if (dbg & 8) ph_t = (long long)__builtin_amdgcn_s_memtime();
       for (;;) {
         const int f = ln < EV2_CWAVES ? flags[ln] : seq;
         if (__all(f >= seq)) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      EV2_MARK(0)
       const int w = tile * EV2_TILE + ln;
       if (ln < EV2_TILE && w < sg.n_windows && !(dbg & 1)) {
         /* ref :142-151: float sum_fft += (double)|X_k|^2 for k = 0..256 in order */
+        /* the chain is ~18 cycles per term (cvt, add, cvt); the LDS reads are blocked 32
+         * terms ahead so that their latency never sits on it */
         const double *tg = terms + ln * 257;
         float sum = 0.f;
-#pragma unroll 8
-        for (int k = 0; k <= 256; ++k) sum = (float)((double)sum + tg[k]);
+        double ta[32], tb2[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) ta[k] = tg[k];
+#pragma unroll 1
+        for (int blk = 0; blk < 8; blk += 2) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) tb2[k] = tg[32 * (blk + 1) + k];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + ta[k]);
+          if (blk + 2 < 8) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) ta[k] = tg[32 * (blk + 2) + k];
+          }
+#pragma unroll
+          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + tb2[k]);
+        }
+        sum = (float)((double)sum + tg[256]);
         energies[sg.env_off + w] = sum;
         lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (ln == 0) flags[8] = seq;
+      EV2_MARK(1)
     }
+    if ((dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && ln == 0)
+      printf("ev2 summing wave (cycles/tile): wait for terms %lld  chain+store %lld\n", ph[0] / n_tiles,
+             ph[1] / n_tiles);
     return;
   }
 
@@ -762,17 +805,23 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   /* the wave's 1280 samples of a round are 160 16-byte chunks: lane ln owns chunks ln,
    * ln + 64 and (ln < 32) ln + 128; they are fetched one round ahead so that the HBM
    * latency hides behind the arithmetic of the current round */
-  uint4 pre[3];
+  /* lane ln owns samples 20*ln .. 20*ln+19 of the wave's 1280 (five 8-byte loads) plus
+   * the one sample that starts its own zero-state output (lane (g, l): sample l of window
+   * g); both are fetched one round ahead so that the HBM latency hides behind the
+   * arithmetic of the current round */
+  uint2 pre[5];
+  short preh;
   auto fetch = [&](int tile_) {
     const int base = (tile_ * EV2_TILE + 4 * wave) * 256;
+    const bool live = tile_ < n_tiles;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int c = ln + 64 * u;
-      const int i0 = base + 8 * c;
-      pre[u] = make_uint4(0, 0, 0, 0);
-      if (c < 160 && tile_ < n_tiles && i0 + 8 <= n_used)
-        pre[u] = *reinterpret_cast<const uint4 *>(p + i0);
+    for (int u = 0; u < 5; ++u) {
+      const int i0 = base + 20 * ln + 4 * u;
+      pre[u] = make_uint2(0, 0);
+      if (live && i0 + 4 <= n_used) pre[u] = *reinterpret_cast<const uint2 *>(p + i0);
     }
+    const int ih = base + 256 * g + l;
+    preh = (live && ih < n_used) ? p[ih] : (short)0;
   };
   fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -782,33 +831,27 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       if (ln == 0) flags[wave] = seq;
       continue;
     }
-    ev2_wave_sync(); /* previous round's LDS reads are complete */
-    /* 1. 1280 samples -> normalised f64 (ref :109-114), 8 per prefetched 16-byte chunk */
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int c = ln + 64 * u;
-      if (c < 160) {
-        const unsigned w[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-          buf[ev2_slot(8 * c + 2 * k)] = bl_norm(lo - mean, vprime, rcp);
-          buf[ev2_slot(8 * c + 2 * k + 1)] = bl_norm(hi - mean, vprime, rcp);
-        }
-      }
-    }
-    fetch(tile + gridDim.x); /* next round's samples */
-    ev2_wave_sync();
-    /* 2. FIR (ref :123-138).  Lane ln produces tile-local outputs 20*ln .. 20*ln+19 from
-     *    samples 20*ln-16 .. 20*ln+19: slots 21*ln .. 21*ln+15 and 21*ln+17 .. 21*ln+36 */
+    if (dbg & 8) ph_t = (long long)__builtin_amdgcn_s_memtime();
+    /* 1. normalise (ref :109-114) straight into registers: r[16..35] = own 20 samples,
+     *    r[0..15] = the previous lane's last 16 (DPP wave shift, no LDS round trip) */
     double yv[20], yh;
     {
       double r[36];
-      const double *ra = buf + 21 * ln;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) r[i] = ra[i];
+      for (int u = 0; u < 5; ++u) {
+        const unsigned w[2] = {pre[u].x, pre[u].y};
 #pragma unroll
-      for (int i = 0; i < 20; ++i) r[16 + i] = ra[17 + i];
+        for (int k = 0; k < 2; ++k) {
+          const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
+          r[16 + 4 * u + 2 * k] = bl_norm(lo - mean, vprime, rcp);
+          r[16 + 4 * u + 2 * k + 1] = bl_norm(hi - mean, vprime, rcp);
+        }
+      }
+      const double xh = bl_norm((int)preh - mean, vprime, rcp);
+      fetch(tile + gridDim.x); /* next round's samples */
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = bl_dpp_f64<0x138>(r[20 + i]); /* wave_shr:1 */
+      /* 2. FIR (ref :123-138): outputs 20*ln .. 20*ln+19 of the wave's 1280 */
 #pragma unroll
       for (int i = 0; i < 20; ++i) {
 #define XR(m) r[i + 16 - (m)]
@@ -816,12 +859,23 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 #undef XR
       }
       /* first 16 outputs of each window start from a zeroed delay line (ref :121):
-       * lane (g, l) filters sample l of window g with the taps that exist */
-#define XH(m) ((l - (m)) >= 0 ? buf[ev2_slot(256 * g + l - (m))] : 0.0)
+       * lane (g, l) filters sample l of window g with the taps that exist; tap m is the
+       * sample of lane l - m of the same 16-lane row, zero when there is none
+       * (DPP row_shr:m with bound_ctrl) */
+      double hx[17];
+      hx[0] = xh;
+      hx[1] = bl_dpp_f64<0x111>(xh);  hx[2] = bl_dpp_f64<0x112>(xh);  hx[3] = bl_dpp_f64<0x113>(xh);
+      hx[4] = bl_dpp_f64<0x114>(xh);  hx[5] = bl_dpp_f64<0x115>(xh);  hx[6] = bl_dpp_f64<0x116>(xh);
+      hx[7] = bl_dpp_f64<0x117>(xh);  hx[8] = bl_dpp_f64<0x118>(xh);  hx[9] = bl_dpp_f64<0x119>(xh);
+      hx[10] = bl_dpp_f64<0x11A>(xh); hx[11] = bl_dpp_f64<0x11B>(xh); hx[12] = bl_dpp_f64<0x11C>(xh);
+      hx[13] = bl_dpp_f64<0x11D>(xh); hx[14] = bl_dpp_f64<0x11E>(xh); hx[15] = bl_dpp_f64<0x11F>(xh);
+      hx[16] = 0.0;
+#define XH(m) hx[m]
       yh = BL_FIR(XH);
 #undef XH
     }
-    ev2_wave_sync(); /* every lane has read its inputs: outputs may overwrite them */
+    EV2_MARK(0) /* normalise + FIR */
+    ev2_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
 #pragma unroll
     for (int i = 0; i < 20; ++i) buf[21 * ln + 17 + i] = yv[i];
     /* sample 256*(g+1)+q (q < 16) is both the tail of window g (steady state, above) and
@@ -838,7 +892,9 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       im[m1] = buf[s + 1];
     }
     ev2_wave_sync(); /* window data is in registers; the slice becomes exchange space */
+    EV2_MARK(1) /* z store + DFT input load */
     bl_fft512_pass1<double>(l, re, im, tw256);
+    EV2_MARK(2) /* pass 1 */
     double *xg = buf + g * 272; /* [16][17] doubles, re then im */
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + l] = re[bl_pos16(k1)];
@@ -852,7 +908,9 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) im[n0] = xg[l * 17 + n0];
     ev2_wave_sync();
+    EV2_MARK(3) /* transposes */
     bl_fft16(re, im);
+    EV2_MARK(4) /* pass 2 */
     /* partner half rows (k0 = 8..15), row stride 9 doubles: re block then im block */
     double *pgr = buf + g * 144, *pgi = buf + 576 + g * 144;
 #pragma unroll
@@ -861,30 +919,45 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       pgi[l * 9 + (k0 - 8)] = im[bl_pos16(k0)];
     }
     ev2_wave_sync();
-    /* 4. the 4 x 257 power terms go straight to the summing wave's buffer once it has
-     *    drained the previous tile */
-    while (flags[8] < seq - 1) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    double *tg = terms + (4 * wave + g) * 257;
+    /* 4. the 4 x 257 power terms are computed first and only then handed to the summing
+     *    wave (once it has drained the previous tile): nothing but the 17 stores per lane
+     *    sits between the two waits of the hand-over */
+    double own[8], mir[8];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
       const int sl = bl_partner_slot(l, k0);
       const int ps = (sl >> 3) * 9 + (sl & 7);
       const double pr = sl < 0 ? re[bl_pos16(0)] : pgr[ps];
       const double pi = sl < 0 ? im[bl_pos16(0)] : pgi[ps];
-      double own, mir;
-      bl_fft512_power1<double>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0], own,
-                               mir);
-      tg[l + 16 * k0] = own;
-      tg[256 - l - 16 * k0] = mir;
+      bl_fft512_power1<double>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
+                               own[k0], mir[k0]);
     }
-    if (l == 0) {
-      const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
-      tg[128] = __builtin_fma(mr, mr, mi * mi);
+    const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
+    const double mid = __builtin_fma(mr, mr, mi * mi);
+    EV2_MARK(7) /* power */
+    while (flags[8] < seq - 1) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    EV2_MARK(6) /* wait for the summing wave */
+    double *tg = terms + (4 * wave + g) * 257;
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+      tg[l + 16 * k0] = own[k0];
+      tg[256 - l - 16 * k0] = mir[k0];
     }
+    if (l == 0) tg[128] = mid;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     ev2_wave_sync();
     if (ln == 0) flags[wave] = seq;
+  }
+  if ((dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && ln == 0 && (wave == 0 || wave == 3))
+    printf("ev2 phases wave %d (cycles/round): fir %lld  zld %lld  pass1 %lld  xch %lld  pass2 %lld  par %lld  "
+           "wait %lld  power %lld\n", wave, ph[0] / n_tiles, ph[1] / n_tiles, ph[2] / n_tiles,
+           ph[3] / n_tiles, ph[4] / n_tiles, ph[5] / n_tiles, ph[6] / n_tiles, ph[7] / n_tiles);
+  if ((dbg & 4) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    const long long c = (long long)__builtin_amdgcn_s_memtime() - dbg_c0;
+    const long long w = (long long)wall_clock64() - dbg_w0;
+    printf("ev2 clock probe: %lld shader cycles in %lld wall ticks (100 MHz) -> %.1f MHz, %d tiles\n", c,
+           w, (double)c / (double)w * 100.0, n_tiles);
   }
 }
 
