@@ -1037,13 +1037,19 @@ __global__ __launch_bounds__(64) void k_env_tail(const bl_dsong *__restrict__ so
   r->atk_sum = t.atk;
   r->v.tempo = bl_tail_tempo(t.beat(), sg.duration);
   r->v.attack = bl_tail_attack(t.atk, sg.n);
-  if (what == 7) {
-    /* ref analyze.c:68-79 */
-    const float rating = (float)(fmax((double)r->v.tempo, 0.0) + (double)r->v.amplitude +
-                                 (double)r->v.frequency + fmax((double)r->v.attack, 0.0));
-    r->force = rating;
-    r->calm_or_loud = rating > 0 ? BL_LOUD : (rating < 0 ? BL_CALM : BL_UNKNOWN);
-  }
+  (void)what;
+}
+
+/* ref analyze.c:63-80: force = fmax(tempo,0) + amplitude + frequency + fmax(attack,0)
+ * (double sum, stored as float), then LOUD / CALM / UNKNOWN by its sign */
+__global__ void k_force(bl_amd_song_result *res, int n_songs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_songs) return;
+  bl_amd_song_result *r = res + i;
+  const float rating = (float)(fmax((double)r->v.tempo, 0.0) + (double)r->v.amplitude +
+                               (double)r->v.frequency + fmax((double)r->v.attack, 0.0));
+  r->force = rating;
+  r->calm_or_loud = rating > 0 ? BL_LOUD : (rating < 0 ? BL_CALM : BL_UNKNOWN);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1167,6 +1173,9 @@ struct Ctx {
   bool env_v1 = false;
   int env_dbg = 0;
   bool fuse_scan = false;
+  hipStream_t side = nullptr; /* envelope tail runs here, beside the frequency pass */
+  hipEvent_t ev_env = nullptr, ev_tail = nullptr;
+  bool side_ok = false;
   long long last_env_total = 0;
   int device = 0;
   int n_cu = 256;
@@ -1260,6 +1269,12 @@ int init_locked(int device) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
+  if (!g.side_ok) {
+    BL_HIP_CHECK(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
+    BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_env, hipEventDisableTiming));
+    BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_tail, hipEventDisableTiming));
+    g.side_ok = true;
+  }
   g.device = device;
   g.ready = true;
   return BL_OK;
@@ -1398,21 +1413,10 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
                      d_stats);
   hipLaunchKernelGGL(k_variance_wrap_finish, dim3(tb64), dim3(64), 0, stream, d_songs, d_stats,
                      n_songs, d_results);
-  if (what & 1) {
-    ProfScope ps(PK_AMP, stream);
-    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, d_songs, d_stats, d_hist,
-                       d_results);
-  }
-  if (what & 2) {
-    if (!fused) {
-      ProfScope ps(PK_FREQ, stream);
-      hipLaunchKernelGGL(k_freq_frames<false>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES,
-                         stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
-    }
-    ProfScope ps(PK_FREQ_FIN, stream);
-    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, d_songs,
-                       d_results);
-  }
+  /* Order: the envelope windows first, then the serial envelope tail on an internal side
+   * stream while the main stream runs the frequency and amplitude kernels (the tail is one
+   * latency-bound wave per 64 songs and leaves the chip free); k_force joins the two. */
+  bool tail_async = false;
   if (what & 4) {
     {
       ProfScope ps(PK_ENV, stream);
@@ -1427,10 +1431,37 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
                            g.env_dbg);
       }
     }
-    ProfScope ps(PK_TAIL, stream);
-    hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(64), 0, stream, d_songs, d_lc, n_songs, d_results,
-                       what);
+    hipStream_t ts = stream;
+    if ((what & 3) && g.side_ok) { /* something to overlap with */
+      BL_HIP_CHECK(hipEventRecord(g.ev_env, stream));
+      BL_HIP_CHECK(hipStreamWaitEvent(g.side, g.ev_env, 0));
+      ts = g.side;
+      tail_async = true;
+    }
+    {
+      ProfScope ps(PK_TAIL, ts);
+      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(64), 0, ts, d_songs, d_lc, n_songs, d_results,
+                         what);
+    }
+    if (tail_async) BL_HIP_CHECK(hipEventRecord(g.ev_tail, g.side));
   }
+  if (what & 2) {
+    if (!fused) {
+      ProfScope ps(PK_FREQ, stream);
+      hipLaunchKernelGGL(k_freq_frames<false>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES,
+                         stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
+    }
+    ProfScope ps(PK_FREQ_FIN, stream);
+    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, d_songs,
+                       d_results);
+  }
+  if (what & 1) {
+    ProfScope ps(PK_AMP, stream);
+    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, d_songs, d_stats, d_hist,
+                       d_results);
+  }
+  if (tail_async) BL_HIP_CHECK(hipStreamWaitEvent(stream, g.ev_tail, 0));
+  if (what == 7) hipLaunchKernelGGL(k_force, dim3(tb64), dim3(64), 0, stream, d_results, n_songs);
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }
@@ -1780,6 +1811,12 @@ void bl_amd_shutdown(void) {
   }
   if (g.tables_mem) (void)hipFree(g.tables_mem);
   g.tables_mem = nullptr;
+  if (g.side_ok) {
+    (void)hipStreamDestroy(g.side);
+    (void)hipEventDestroy(g.ev_env);
+    (void)hipEventDestroy(g.ev_tail);
+    g.side_ok = false;
+  }
   g.ready = false;
 }
 
