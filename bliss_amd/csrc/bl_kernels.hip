@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -59,6 +60,8 @@ struct bl_dsong {
   int nb_frames; /* 2 * floor(n / 512)                ref tempo_atk_sort.c:63-64 */
   int n_windows; /* nb_frames - 2 windows of hop 256  ref tempo_atk_sort.c:66-67,120 */
   int part_off;  /* first partial-spectrum slot of this song (256 frames per slot) */
+  int out_idx;   /* result slot = position in the caller's order (records are length-sorted) */
+  int pad;
 };
 
 struct bl_dstats {
@@ -206,7 +209,7 @@ __global__ void k_song_prep(const bl_dsong *__restrict__ songs, bl_dstats *stats
     prep_finish(s, n);
   }
   stats[i] = s;
-  bl_amd_song_result *r = res + i;
+  bl_amd_song_result *r = res + sg.out_idx;
   r->start = (int)s.first; r->end = s.last;
   r->mean = s.mean; r->variance = s.variance;
   r->n_frames = sg.n_frames; r->nb_frames = sg.nb_frames; r->n_windows = sg.n_windows;
@@ -243,8 +246,8 @@ __global__ void k_variance_wrap_finish(const bl_dsong *__restrict__ songs, bl_ds
   s.variance = (int)(s.wrap_acc / songs[i].n);
   prep_finish(s, songs[i].n);
   stats[i] = s;
-  res[i].variance = s.variance;
-  res[i].status = s.status;
+  res[songs[i].out_idx].variance = s.variance;
+  res[songs[i].out_idx].status = s.status;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__
   if (tid == 0) {
     float integral = 0;
     for (int i = BL_INT_LO; i <= BL_INT_HI; ++i) integral += v[i];
-    bl_amd_song_result *r = res + song;
+    bl_amd_song_result *r = res + songs[song].out_idx;
     r->hist_integral = integral;
     r->v.amplitude = -0.2f * integral + 6.0f; /* ref :79 */
   }
@@ -501,8 +504,9 @@ __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ p
     for (int i = 119; i <= 234; ++i) b4 += ps[i];
     b4 /= 115;
     const float sum = b4 + b3 + b2 - b0 - b1;
-    res[song].freq_peak = peak;
-    res[song].v.frequency = (float)((1. / 3.) * (double)sum + 68. / 3.);
+    bl_amd_song_result *r = res + songs[song].out_idx;
+    r->freq_peak = peak;
+    r->v.frequency = (float)((1. / 3.) * (double)sum + 68. / 3.);
   }
 }
 
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__(64) void k_env_tail(const bl_dsong *__restrict__ so
     __syncthreads();
   }
   if (!valid) return;
-  bl_amd_song_result *r = res + song;
+  bl_amd_song_result *r = res + sg.out_idx;
   r->beat = t.beat();
   r->atk_sum = t.atk;
   r->v.tempo = bl_tail_tempo(t.beat(), sg.duration);
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_synth(int16_t *pcm, const bl_dsong *__r
                                                unsigned seed_base, unsigned rate) {
   const bl_dsong sg = songs[blockIdx.y];
   int16_t *p = pcm + sg.pcm_off;
-  const unsigned seed = seed_base + blockIdx.y;
+  const unsigned seed = seed_base + (unsigned)sg.out_idx; /* records may be length-sorted */
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)sg.n; i += gridDim.x * 256u)
     p[i] = syn_sample(seed, rate, (unsigned)sg.channels, i);
 }
@@ -1338,11 +1342,23 @@ int fill_songs(const bl_amd_song_desc *desc, int n_songs, std::vector<bl_dsong> 
     s.n_windows = s.nb_frames - 2;
     s.env_off = env_total;
     s.part_off = (int)parts;
+    s.out_idx = i;
+    s.pad = 0;
     parts += (s.n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
     env_total += s.nb_frames;
     if (d.n_samples > max_n) max_n = d.n_samples;
   }
   if (parts_total) *parts_total = parts;
+  /* Mixed-length corpora: process the records longest first.  The 64 songs that share a
+   * wave of k_env_tail then have similar lengths (its straight-line steady-state path is
+   * wave-uniform), and the long songs do not straggle at the end of the per-song grids.
+   * Results go back to the caller's order through out_idx; scratch offsets keep the
+   * caller's order too.  Equal lengths: the order is left alone. */
+  bool mixed = false;
+  for (int i = 1; i < n_songs && !mixed; ++i) mixed = out[i].n != out[0].n;
+  if (mixed)
+    std::stable_sort(out.begin(), out.end(),
+                     [](const bl_dsong &a, const bl_dsong &b) { return a.n > b.n; });
   return BL_OK;
 }
 
