@@ -126,3 +126,18 @@ def distance_matrix(vecs):
 def cosine_matrix(vecs):
     """N x N bl_cosine_similarity matrix (ref src/analyze.c:135-140)."""
     return _matrix("bl_amd_cosine_matrix_host", vecs)
+
+
+def playlist(vecs, seed_index):
+    """Song indices ordered by increasing bl_distance from song `seed_index`, and the
+    distances (ref python/examples/make_m3u_playlist.py:62-72).  Stable for ties."""
+    lib = _lib.load()
+    v = np.ascontiguousarray(vecs, dtype=np.float32).reshape(-1, 4)
+    n = v.shape[0]
+    order = np.empty(n, dtype=np.int32)
+    dist = np.empty(n, dtype=np.float32)
+    rc = lib.bl_amd_playlist_host(v.ctypes.data_as(C.POINTER(_lib.ForceVector)), n, int(seed_index),
+                                  order.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  dist.ctypes.data_as(C.POINTER(C.c_float)))
+    _check(rc, "bl_amd_playlist_host")
+    return order, dist

@@ -83,6 +83,14 @@ int bl_amd_cosine_matrix_device(const struct force_vector_s *d_vecs, int n, int 
 int bl_amd_distance_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out);
 int bl_amd_cosine_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out);
 
+/* Seeded playlist (ref python/examples/make_m3u_playlist.py:62-72): d_dist[j] =
+ * bl_distance(vecs[seed_index], vecs[j]) and d_order = the song indices by increasing
+ * distance (stable: ties by index).  d_order: n int32, d_dist: n floats. */
+int bl_amd_playlist_device(const struct force_vector_s *d_vecs, int n, int seed_index,
+                           int32_t *d_order, float *d_dist, void *stream);
+int bl_amd_playlist_host(const struct force_vector_s *h_vecs, int n, int seed_index,
+                         int32_t *h_order, float *h_dist /* may be NULL */);
+
 /* Integer-only synthetic PCM (the benchmark corpus of BASELINE.json),
  * generated in place on the device: song i = seed_base + i, written at
  * h_desc[i].pcm_offset.  Byte-identical to oracle/orc_synth.c. */

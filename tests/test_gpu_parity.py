@@ -255,3 +255,37 @@ def test_repeatability_and_order_independence(gpu_lib):
     for k in r1.dtype.names:
         assert np.array_equal(r1[k], r2[k]), k
         assert r1[k][0] == rb[k][1], k
+
+
+def test_playlist_matches_reference_recipe(gpu_lib, oracle):
+    """ref python/examples/make_m3u_playlist.py:62-72 (numpy L2 from the seed + argsort)."""
+    rng = np.random.default_rng(12)
+    v = (rng.standard_normal((5000, 4)) * 6).astype(np.float32)
+    v[100] = v[7]; v[4000] = v[7]          # exact ties
+    order, dist = bliss_amd.playlist(v, 7)
+    want = np.array([oracle.distance(v[7], x) for x in v], dtype=np.float32)
+    assert np.array_equal(dist, want)
+    assert np.array_equal(order, np.argsort(want, kind="stable"))
+    assert order[0] == 7 and list(order[1:3]) == [100, 4000]
+
+
+def test_python_surface_mirrors_reference(gpu_lib):
+    """ref python/bliss/bl_song.py + distance.py usage patterns."""
+    f = os.path.join(HERE, "golden", "song.flac")
+    with bliss_amd.bl_song(f) as song:
+        assert song["duration"] == 11 and song["artist"] == "David TMX"
+        fv = song["force_vector"]
+        assert set(fv) == {"tempo", "amplitude", "frequency", "attack"}
+        assert abs(fv["tempo"] - (-8.945454)) <= 1e-5
+        assert len(song) == 17 and "force_vector" in list(song)
+        env = song.envelope_analysis()
+        assert env["tempo"] == fv["tempo"] and env["attack"] == fv["attack"]
+        assert song.amplitude_analysis() == fv["amplitude"]
+        other = bliss_amd.bl_song(initializer={"force_vector": fv})
+        assert bliss_amd.distance.distance(song, other)["distance"] == 0.0
+        assert abs(bliss_amd.distance.cosine_similarity(song, other)["similarity"] - 1.0) < 1e-6
+    d = bliss_amd.distance.distance(f, f)
+    assert d["distance"] == 0.0 and d["song1"]["title"] == "Renaissance"
+    d["song1"].free(); d["song2"].free()
+    assert bliss_amd.distance.distance(1, 2) == {"distance": None, "song1": None, "song2": None}
+    assert abs(bliss_amd.version.version() - 1.2) < 1e-6
