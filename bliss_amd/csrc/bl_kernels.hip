@@ -94,6 +94,7 @@ typedef bl_c2<float> c2f;
 /* ------------------------------------------------------------------------- */
 /* k_pcm_scan                                                                 */
 
+template <bool HIST = true>
 __device__ __forceinline__ void scan_sample(int s, unsigned idx, long long &sum,
                                             unsigned long long &sq, unsigned &first, int &last,
                                             unsigned *lh) {
@@ -103,10 +104,13 @@ __device__ __forceinline__ void scan_sample(int s, unsigned idx, long long &sum,
     first = min(first, idx);
     last = max(last, (int)idx);
   }
-  const unsigned b = (unsigned)(s + BL_HIST_BINS / 2);
-  if (b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
+  if (HIST) {
+    const unsigned b = (unsigned)(s + BL_HIST_BINS / 2);
+    if (b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
+  }
 }
 
+template <bool HIST>
 __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pcm,
                                                   const bl_dsong *__restrict__ songs,
                                                   bl_dstats *stats, unsigned *hist) {
@@ -129,13 +133,13 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pc
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-      scan_sample(lo, 8u * v + 2u * k, sum, sq, first, last, lh);
-      scan_sample(hi, 8u * v + 2u * k + 1u, sum, sq, first, last, lh);
+      scan_sample<HIST>(lo, 8u * v + 2u * k, sum, sq, first, last, lh);
+      scan_sample<HIST>(hi, 8u * v + 2u * k + 1u, sum, sq, first, last, lh);
     }
   }
   if (blockIdx.x == 0 && tid < (sg.n & 7)) {
     const unsigned idx = 8u * nvec + tid;
-    scan_sample((int)p[idx], idx, sum, sq, first, last, lh);
+    scan_sample<HIST>((int)p[idx], idx, sum, sq, first, last, lh);
   }
   /* wave reduction, then one set of atomics per wave */
 #pragma unroll
@@ -719,9 +723,14 @@ __device__ __forceinline__ void ev2_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* DBG = true adds the measurement aids of BL_AMD_ENV_DBG (bit 0: skip the ordered sums,
+ * bit 1: skip the compute, bit 2: clock probe, bit 3: per-phase cycle counts); the
+ * production instantiation carries none of it (device printf alone costs registers). */
+template <bool DBG>
 __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
-    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc, int dbg) {
+    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc, int dbg_arg) {
+  const int dbg = DBG ? dbg_arg : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *terms = reinterpret_cast<double *>(smem + EV2_TERMS_OFF); /* [EV2_TILE][257] */
   c2d *tw256 = reinterpret_cast<c2d *>(smem + EV2_TW_OFF);
@@ -744,20 +753,20 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long ph_t = 0;
 #define EV2_MARK(i)                                                     \
-  if (dbg & 8) {                                                        \
+  if (DBG && (dbg & 8)) {                                               \
     const long long now_ = (long long)__builtin_amdgcn_s_memtime();     \
     ph[i] += now_ - ph_t;                                               \
     ph_t = now_;                                                        \
   }
-  const long long dbg_c0 = (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  const long long dbg_w0 = (dbg & 4) ? (long long)wall_clock64() : 0;
+  const long long dbg_c0 = (DBG && (dbg & 4)) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  const long long dbg_w0 = (DBG && (dbg & 4)) ? (long long)wall_clock64() : 0;
 
   if (wave == EV2_CWAVES) {
     /* ---- summing wave ---- */
     __builtin_amdgcn_s_setprio(3);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       ++seq;
-      if (dbg & 8) ph_t = (long long)__builtin_amdgcn_s_memtime();
+      if (DBG && (dbg & 8)) ph_t = (long long)__builtin_amdgcn_s_memtime();
       for (;;) {
         const int f = ln < EV2_CWAVES ? flags[ln] : seq;
         if (__all(f >= seq)) break;
@@ -796,6 +805,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       if (ln == 0) flags[8] = seq;
       EV2_MARK(1)
     }
+    if constexpr (DBG)
     if ((dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && ln == 0)
       printf("ev2 summing wave (cycles/tile): wait for terms %lld  chain+store %lld\n", ph[0] / n_tiles,
              ph[1] / n_tiles);
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       if (ln == 0) flags[wave] = seq;
       continue;
     }
-    if (dbg & 8) ph_t = (long long)__builtin_amdgcn_s_memtime();
+    if (DBG && (dbg & 8)) ph_t = (long long)__builtin_amdgcn_s_memtime();
     /* 1. normalise (ref :109-114) straight into registers: r[16..35] = own 20 samples,
      *    r[0..15] = the previous lane's last 16 (DPP wave shift, no LDS round trip) */
     double yv[20], yh;
@@ -953,10 +963,12 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     ev2_wave_sync();
     if (ln == 0) flags[wave] = seq;
   }
+  if constexpr (DBG)
   if ((dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && ln == 0 && (wave == 0 || wave == 3))
     printf("ev2 phases wave %d (cycles/round): fir %lld  zld %lld  pass1 %lld  xch %lld  pass2 %lld  par %lld  "
            "wait %lld  power %lld\n", wave, ph[0] / n_tiles, ph[1] / n_tiles, ph[2] / n_tiles,
            ph[3] / n_tiles, ph[4] / n_tiles, ph[5] / n_tiles, ph[6] / n_tiles, ph[7] / n_tiles);
+  if constexpr (DBG)
   if ((dbg & 4) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     const long long c = (long long)__builtin_amdgcn_s_memtime() - dbg_c0;
     const long long w = (long long)wall_clock64() - dbg_w0;
@@ -1291,7 +1303,9 @@ int init_locked(int device) {
   g.tb.log101 = log((double)(1 + 100.0f)); /* ref tempo_atk_sort.c:188, log(1 + mu) */
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_ENV_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2),
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   {
     const char *v = getenv("BL_AMD_ENV_V1"); /* A/B switch for measurements only */
@@ -1452,7 +1466,11 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
                        stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
   } else {
     ProfScope ps(PK_SCAN, stream);
-    hipLaunchKernelGGL(k_pcm_scan, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm, d_songs,
+    if (getenv("BL_AMD_SCAN_NOHIST")) /* measurement aid: cost of the LDS histogram */
+      hipLaunchKernelGGL(k_pcm_scan<false>, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm,
+                         d_songs, d_stats, d_hist);
+    else
+    hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm, d_songs,
                        d_stats, d_hist);
   }
   hipLaunchKernelGGL(k_song_prep, dim3(tb64), dim3(64), 0, stream, d_songs, d_stats, n_songs,
@@ -1474,9 +1492,13 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
       } else {
         /* one 512-thread workgroup per CU; blocks of a song split its 28-window tiles */
         const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2);
-        hipLaunchKernelGGL(k_env_windows2, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                           EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc,
-                           g.env_dbg);
+        if (g.env_dbg)
+          hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                             EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc,
+                             g.env_dbg);
+        else
+          hipLaunchKernelGGL(k_env_windows2<false>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                             EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc, 0);
       }
     }
     hipStream_t ts = stream;
@@ -1818,7 +1840,7 @@ int bld_mean_variance_host(const int16_t *h_pcm, int n, int have_mean, int mean_
   const bl_dsong *d_songs = static_cast<const bl_dsong *>(g.songs.p);
   const int gx = grid_x_for(((long long)n / 8 + 255) / 256, 1, 8);
   hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(64), 0, nullptr, d_stats, 1);
-  hipLaunchKernelGGL(k_pcm_scan, dim3(gx, 1), dim3(256), 0, nullptr,
+  hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx, 1), dim3(256), 0, nullptr,
                      static_cast<const int16_t *>(g.arena[0].p), d_songs, d_stats,
                      static_cast<unsigned *>(g.hist.p));
   bl_dstats st;

@@ -289,3 +289,26 @@ def test_python_surface_mirrors_reference(gpu_lib):
     d["song1"].free(); d["song2"].free()
     assert bliss_amd.distance.distance(1, 2) == {"distance": None, "song1": None, "song2": None}
     assert abs(bliss_amd.version.version() - 1.2) < 1e-6
+
+
+def test_extreme_amplitudes(gpu_lib, oracle):
+    """Full-scale clipping, a very quiet song and a DC-heavy one: large / tiny variances
+    stress the normalisation (exact quotient), the f32-rounded energy sums and the
+    amplitude histogram saturation paths."""
+    rng = np.random.default_rng(21)
+    n = 22050 * 2 * 12
+    loud = (rng.integers(0, 2, n) * 2 - 1).astype(np.int16) * 32767          # +-32767 square noise
+    loud[::7] = -32768
+    quiet = rng.integers(-3, 4, n).astype(np.int16)                          # +-3 LSB
+    quiet[0] = 1; quiet[-1] = -2
+    sparse = np.zeros(n, dtype=np.int16)                                     # mostly digital silence
+    sparse[1000:200000:37] = rng.integers(-20000, 20000, len(range(1000, 200000, 37))).astype(np.int16)
+    songs = [loud, quiet, sparse]
+    got = bliss_amd.analyze_batch_host(songs, 2, 12)
+    for i, s16 in enumerate(songs):
+        ref = oracle.analyze(s16, 2, 12)
+        for k in INTS:
+            assert int(got[i][k]) == int(ref[k]), (i, k, int(got[i][k]), int(ref[k]))
+        for k in FLOATS:
+            a, b = float(got[i][k]), float(ref[k])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= REL * max(abs(b), 1e-6), (i, k, a, b)
