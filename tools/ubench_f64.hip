@@ -1,6 +1,8 @@
 // Micro-benchmark of f64 / conversion latency and issue rate on gfx950 (one wave, then 2 waves per SIMD).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/ubench_f64.hip -o /tmp/ubench && /tmp/ubench
 #include <hip/hip_runtime.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
 #include <cstdio>
 #define N 4096
 template <int MODE> __global__ void k(double *out, long long *cyc, double a, double b) {
@@ -34,7 +36,7 @@ template <int MODE> void run(const char *name, int ops, int threads) {
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  for (int th : {64, 512}) {
+  for (int th : {64, 512, 1024}) {
     run<0>("dep v_add_f64", 1, th); run<1>("dep v_mul_f64", 1, th); run<2>("dep v_fma_f64", 1, th);
     run<3>("ordered-sum step (3 ops)", 3, th); run<5>("cvt,cvt,add via double", 3, th);
     run<6>("dep cvt f64->f32->f64", 2, th); run<9>("4 indep cvt pairs", 8, th);
