@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbliss_amd.so")
+# BLISS_AMD_LIB: load another build of the same C-ABI (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("BLISS_AMD_LIB") or os.path.join(_HERE, "libbliss_amd.so")
 
 BL_LOUD, BL_CALM, BL_UNKNOWN, BL_UNEXPECTED, BL_OK = 0, 1, 2, -2, 0
 

@@ -735,9 +735,12 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   double *terms = reinterpret_cast<double *>(smem + EV2_TERMS_OFF); /* [EV2_TILE][257] */
   c2d *tw256 = reinterpret_cast<c2d *>(smem + EV2_TW_OFF);
   c2d *tw512 = tw256 + 256;
-  volatile int *flags = reinterpret_cast<volatile int *>(smem + EV2_FLAG_OFF);
   /* flags[0..6]: last tile sequence whose terms compute wave c has published;
-   * flags[8]: last tile sequence the summing wave has consumed */
+   * flags[8]: last tile sequence the summing wave has consumed.  Typed as LDS (address
+   * space 3) so that the polls are ds_read_b32: through a generic volatile pointer hipcc
+   * emits flat loads with sc0 sc1 and waits on vmcnt as well. */
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  lds_vint *flags = (lds_vint *)(smem + EV2_FLAG_OFF);
 
   const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63, g = ln >> 4, l = ln & 15;
   const bl_dsong sg = songs[blockIdx.y];
@@ -754,9 +757,11 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   long long ph_t = 0;
 #define EV2_MARK(i)                                                     \
   if (DBG && (dbg & 8)) {                                               \
+    __builtin_amdgcn_sched_barrier(0);                                  \
     const long long now_ = (long long)__builtin_amdgcn_s_memtime();     \
     ph[i] += now_ - ph_t;                                               \
     ph_t = now_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                  \
   }
   const long long dbg_c0 = (DBG && (dbg & 4)) ? (long long)__builtin_amdgcn_s_memtime() : 0;
   const long long dbg_w0 = (DBG && (dbg & 4)) ? (long long)wall_clock64() : 0;
@@ -825,17 +830,23 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
    * arithmetic of the current round */
   uint2 pre[5];
   short preh;
+  /* The loads are unconditional (addresses clamped into the song, values zeroed by a
+   * select afterwards): with exec-masked loads hipcc cannot count what is outstanding and
+   * waits vmcnt(0) right after issuing the NEXT round's loads. */
   auto fetch = [&](int tile_) {
     const int base = (tile_ * EV2_TILE + 4 * wave) * 256;
     const bool live = tile_ < n_tiles;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int i0 = base + 20 * ln + 4 * u;
-      pre[u] = make_uint2(0, 0);
-      if (live && i0 + 4 <= n_used) pre[u] = *reinterpret_cast<const uint2 *>(p + i0);
+      const bool ok = live && i0 + 4 <= n_used;
+      const uint2 v = *reinterpret_cast<const uint2 *>(p + (ok ? i0 : 0));
+      pre[u] = ok ? v : make_uint2(0, 0);
     }
     const int ih = base + 256 * g + l;
-    preh = (live && ih < n_used) ? p[ih] : (short)0;
+    const bool okh = live && ih < n_used;
+    const short vh = p[okh ? ih : 0];
+    preh = okh ? vh : (short)0;
   };
   fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -949,7 +960,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
     const double mid = __builtin_fma(mr, mr, mi * mi);
     EV2_MARK(7) /* power */
-    while (flags[8] < seq - 1) __builtin_amdgcn_s_sleep(1);
+    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     EV2_MARK(6) /* wait for the summing wave */
     double *tg = terms + (4 * wave + g) * 257;
