@@ -108,7 +108,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or under_launcher:  # torchrun: RCCL group even at world size 1
         dist.init_process_group("nccl", device_id=dev)
 
     import bliss_amd
@@ -129,7 +130,7 @@ def main():
     if songs > fit:
         songs = max(1, 1 << (max(fit, 1).bit_length() - 1))
         capped = True
-    if world > 1:  # every rank uses the smallest count any rank can hold
+    if dist.is_initialized():  # every rank uses the smallest count any rank can hold
         t = torch.tensor([songs], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         songs = int(t.item())
@@ -156,7 +157,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -171,7 +172,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.bl_amd_profile(0)
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -267,7 +268,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "songs/s", "cores": os.cpu_count(),
                                         "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

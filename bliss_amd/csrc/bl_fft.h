@@ -98,7 +98,9 @@ template <typename T> BL_HD void bl_fft16(T (&re)[16], T (&im)[16]) {
 /*
  * Phase A (per lane n0): registers hold z[16*m1 + n0], m1 = 0..15.
  * Does pass 1, applies W256^(n0*k1) and writes row-major [k1][n0] (stride 17).
- * tw256: table of W256^e = exp(-2 pi i e/256), e = 0..255.
+ * tw256: twiddles laid out per use, tw256[k1 * 16 + n0] = exp(-2 pi i n0 k1 / 256): the 16
+ * lanes of a group read consecutive 16-byte entries (indexing by the exponent n0*k1 put
+ * lanes l and l + 64/k1 on the same banks: up to 8-way LDS conflicts).
  */
 template <typename T>
 BL_HD void bl_fft512_phaseA(int n0, T (&re)[16], T (&im)[16], const bl_c2<T> *tw256,
@@ -109,7 +111,7 @@ BL_HD void bl_fft512_phaseA(int n0, T (&re)[16], T (&im)[16], const bl_c2<T> *tw
     const int p = bl_pos16(k1);
     T r = re[p], i = im[p];
     if (k1 != 0) {
-      bl_c2<T> w = tw256[(n0 * k1) & 255];
+      bl_c2<T> w = tw256[k1 * 16 + n0];
       if (n0 != 0) bl_cmul(r, i, w.re, w.im);
     }
     bl_c2<T> v; v.re = r; v.im = i;
@@ -204,7 +206,7 @@ BL_HD void bl_fft512_pass1(int n0, T (&re)[16], T (&im)[16], const bl_c2<T> *tw2
 #pragma unroll
   for (int k1 = 1; k1 < 16; ++k1) {
     const int p = bl_pos16(k1);
-    const bl_c2<T> w = tw256[(n0 * k1) & 255];
+    const bl_c2<T> w = tw256[k1 * 16 + n0];
     T r = re[p], i = im[p];
     bl_cmul(r, i, w.re, w.im);
     if (n0 != 0) { re[p] = r; im[p] = i; }

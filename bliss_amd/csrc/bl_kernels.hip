@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
   const bl_dsong sg = songs[blockIdx.y];
   const int16_t *p = pcm + sg.pcm_off;
-  tw256[tid] = tb.tw256_f[tid];
+  tw256[tid] = tb.tw256_f[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
   tw512[tid] = tb.tw512_f[tid];
   hann[tid] = tb.hann[tid];
   hann[tid + 256] = tb.hann[tid + 256];
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void k_env_windows(const int16_t *__restrict__
   const int16_t *p = pcm + sg.pcm_off;
   const int mean = st.mean;
   const double vprime = st.vprime, rcp = st.rcp;
-  tw256[tid] = tb.tw256_d[tid];
+  tw256[tid] = tb.tw256_d[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout */
   tw512[tid] = tb.tw512_d[tid];
   if (tid < 16) xs[tid] = 0.0; /* never-used left margin of the FIR registers */
   const int n_tiles = (sg.n_windows + BL_TILE_W - 1) / BL_TILE_W;
@@ -746,7 +746,10 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   const bl_dsong sg = songs[blockIdx.y];
   const bl_dstats st = stats[blockIdx.y];
   const int16_t *p = pcm + sg.pcm_off;
-  if (tid < 256) { tw256[tid] = tb.tw256_d[tid]; tw512[tid] = tb.tw512_d[tid]; }
+  if (tid < 256) {
+    tw256[tid] = tb.tw256_d[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
+    tw512[tid] = tb.tw512_d[tid];
+  }
   if (tid < 16) flags[tid] = 0;
   __syncthreads();
 

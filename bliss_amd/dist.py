@@ -41,7 +41,7 @@ def gather_force_vectors(local_vecs, counts, group=None):
 
     world = len(counts)
     total = sum(counts)
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():  # plain single-process run
         return local_vecs.clone()
     out = torch.empty((total, 4), dtype=local_vecs.dtype, device=local_vecs.device)
     if len(set(counts)) == 1:

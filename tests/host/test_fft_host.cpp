@@ -11,7 +11,8 @@ template <typename T> static double run(unsigned seed) {
   std::vector<bl_c2<T>> tw256(256), tw512(256), xch(BL_FFT_XCH_ELEMS), par(BL_FFT_PAR_ELEMS);
   const double pi = 3.14159265358979323846;
   for (int e = 0; e < 256; ++e) {
-    tw256[e].re = (T)cos(2 * pi * e / 256); tw256[e].im = (T)-sin(2 * pi * e / 256);
+    const int ex = ((e & 15) * (e >> 4)) & 255;  // tw256 is laid out [k1][n0] -> exponent n0*k1
+    tw256[e].re = (T)cos(2 * pi * ex / 256); tw256[e].im = (T)-sin(2 * pi * ex / 256);
     tw512[e].re = (T)cos(2 * pi * e / 512); tw512[e].im = (T)-sin(2 * pi * e / 512);
   }
   std::vector<double> x(512);
