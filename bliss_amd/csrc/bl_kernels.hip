@@ -696,10 +696,11 @@ __global__ __launch_bounds__(256) void k_env_windows(const int16_t *__restrict__
  */
 #define EV2_CWAVES 7
 #define EV2_TILE (4 * EV2_CWAVES)            /* windows per tile */
-#define EV2_SLOTS 1424                       /* 17 + 1280 samples + 63 pads, + 4 x 16 window heads */
-#define EV2_HEADS 1360
+#define EV2_SLOTS 1490                       /* 18 + 1280 samples + 2 x 64 pads, + 4 x 16 window heads */
+#define EV2_HEADS 1426
+#define EV2_TROW 258                         /* terms row stride (doubles): even -> 16-byte rows */
 #define EV2_TERMS_OFF (EV2_CWAVES * EV2_SLOTS * 8)
-#define EV2_TW_OFF (EV2_TERMS_OFF + EV2_TILE * 257 * 8)
+#define EV2_TW_OFF (EV2_TERMS_OFF + EV2_TILE * EV2_TROW * 8)
 #define EV2_FLAG_OFF (EV2_TW_OFF + 2 * 256 * 16)
 #define EV2_LDS_BYTES (EV2_FLAG_OFF + 64)
 
@@ -713,9 +714,11 @@ template <int CTRL> __device__ __forceinline__ double bl_dpp_f64(double v) {
   return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
-/* LDS slot of tile-local sample j of a compute wave: one pad after every 20 samples
- * makes the per-lane stride 21 doubles (42 banks) -> conflict-free b64 accesses */
-__device__ __forceinline__ int ev2_slot(int j) { return 17 + j + ((j * 3277) >> 16); }
+/* LDS slot of tile-local sample j of a compute wave: two pads after every 20 samples make
+ * the per-lane stride 22 doubles (44 banks: conflict-free 16-byte stores per 8-lane group)
+ * and keep every even sample 16-byte aligned, so that the (re, im) = (y[2m], y[2m+1]) pairs
+ * of the DFT input are single ds_read_b128 (4 LDS cycles instead of the 8 of ds_read2_b64) */
+__device__ __forceinline__ int ev2_slot(int j) { return 18 + j + 2 * ((j * 3277) >> 16); }
 
 __device__ __forceinline__ void ev2_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
         /* ref :142-151: float sum_fft += (double)|X_k|^2 for k = 0..256 in order */
         /* the chain is ~18 cycles per term (cvt, add, cvt); the LDS reads are blocked 32
          * terms ahead so that their latency never sits on it */
-        const double *tg = terms + ln * 257;
+        const double *tg = terms + ln * EV2_TROW;
         float sum = 0.f;
         double ta[32], tb2[32];
 #pragma unroll
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     EV2_MARK(0) /* normalise + FIR */
     ev2_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
 #pragma unroll
-    for (int i = 0; i < 20; ++i) buf[21 * ln + 17 + i] = yv[i];
+    for (int i = 0; i < 20; ++i) buf[22 * ln + 18 + i] = yv[i];
     /* sample 256*(g+1)+q (q < 16) is both the tail of window g (steady state, above) and
      * the head of window g+1 (zero state): heads live in their own 4 x 16 area */
     buf[EV2_HEADS + ln] = yh;
@@ -923,29 +926,31 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     EV2_MARK(1) /* z store + DFT input load */
     bl_fft512_pass1<double>(l, re, im, tw256);
     EV2_MARK(2) /* pass 1 */
-    double *xg = buf + g * 272; /* [16][17] doubles, re then im */
+    /* transposes: rows of 18 doubles so that a lane reads its row as 8 aligned 16-byte
+     * loads (ds_read_b128: 4 LDS cycles; the ds_read2_b64 hipcc picks for unaligned pairs
+     * costs 16).  Layouts checked with tools/lds_model.py: conflict-free. */
+    double *xg = buf + g * 288; /* [16][18] doubles, re then im */
+    const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + l] = re[bl_pos16(k1)];
+    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = re[bl_pos16(k1)];
     ev2_wave_sync();
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) re[n0] = xg[l * 17 + n0];
+    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; re[2 * q] = v.x; re[2 * q + 1] = v.y; }
     ev2_wave_sync();
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + l] = im[bl_pos16(k1)];
+    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = im[bl_pos16(k1)];
     ev2_wave_sync();
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) im[n0] = xg[l * 17 + n0];
+    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
     ev2_wave_sync();
     EV2_MARK(3) /* transposes */
     bl_fft16(re, im);
     EV2_MARK(4) /* pass 2 */
-    /* partner half rows (k0 = 8..15), row stride 9 doubles: re block then im block */
-    double *pgr = buf + g * 144, *pgi = buf + 576 + g * 144;
+    /* partner half rows (k0 = 8..15) as (re, im) pairs, 9 pairs per lane row */
+    double2 *pg = reinterpret_cast<double2 *>(buf) + g * 144;
 #pragma unroll
-    for (int k0 = 8; k0 < 16; ++k0) {
-      pgr[l * 9 + (k0 - 8)] = re[bl_pos16(k0)];
-      pgi[l * 9 + (k0 - 8)] = im[bl_pos16(k0)];
-    }
+    for (int k0 = 8; k0 < 16; ++k0)
+      pg[l * 9 + (k0 - 8)] = make_double2(re[bl_pos16(k0)], im[bl_pos16(k0)]);
     ev2_wave_sync();
     /* 4. the 4 x 257 power terms are computed first and only then handed to the summing
      *    wave (once it has drained the previous tile): nothing but the 17 stores per lane
@@ -954,9 +959,8 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
       const int sl = bl_partner_slot(l, k0);
-      const int ps = (sl >> 3) * 9 + (sl & 7);
-      const double pr = sl < 0 ? re[bl_pos16(0)] : pgr[ps];
-      const double pi = sl < 0 ? im[bl_pos16(0)] : pgi[ps];
+      double pr = re[bl_pos16(0)], pi = im[bl_pos16(0)];
+      if (sl >= 0) { const double2 v = pg[(sl >> 3) * 9 + (sl & 7)]; pr = v.x; pi = v.y; }
       bl_fft512_power1<double>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
                                own[k0], mir[k0]);
     }
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     EV2_MARK(6) /* wait for the summing wave */
-    double *tg = terms + (4 * wave + g) * 257;
+    double *tg = terms + (4 * wave + g) * EV2_TROW;
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
       tg[l + 16 * k0] = own[k0];
