@@ -91,6 +91,14 @@ typedef bl_c2<float> c2f;
 #define BL_C7 0.0882711
 #define BL_C8 0.9065095
 
+/* ordering point between LDS accesses of different lanes of ONE wave: a wave's LDS
+ * instructions execute in order, so only the compiler has to be told */
+__device__ __forceinline__ void bl_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 /* ------------------------------------------------------------------------- */
 /* k_pcm_scan                                                                 */
 
@@ -419,10 +427,12 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) { re[m1] = 0.f; im[m1] = 0.f; }
       }
+      /* the exchange buffers of a 16-lane group are private to it, hence to its wave: no
+       * workgroup barrier inside the frame loop, the four waves drift apart freely */
       bl_fft512_phaseA<float>(l, re, im, tw256, gx);
-      __syncthreads();
+      bl_wave_sync();
       bl_fft512_phaseB<float>(l, re, im, gx, gp);
-      __syncthreads();
+      bl_wave_sync();
       float own[8], mir[8], mid;
       bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
       if (active) { /* ref :88-93: power_spectrum[d] += re*re + im*im */
@@ -430,8 +440,9 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
         for (int k = 0; k < 8; ++k) { a_own[k] += own[k]; a_mir[k] += mir[k]; }
         a_mid += mid;
       }
-      __syncthreads();
+      bl_wave_sync();
     }
+    __syncthreads(); /* every wave is out of its exchanges: the region becomes `red` */
     /* fold the 16 groups of the block in a fixed order */
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -720,6 +731,17 @@ template <int CTRL> __device__ __forceinline__ double bl_dpp_f64(double v) {
  * of the DFT input are single ds_read_b128 (4 LDS cycles instead of the 8 of ds_read2_b64) */
 __device__ __forceinline__ int ev2_slot(int j) { return 18 + j + 2 * ((j * 3277) >> 16); }
 
+/* Hand-over fences between waves of one workgroup: everything handed over lives in LDS, so
+ * only the LDS counter has to drain.  A workgroup-scope fence also waits for vmcnt(0), i.e.
+ * for the summing wave's global stores of the finished energies (and for prefetches in
+ * flight) — ~1.5 k cycles of HBM latency on the critical path of every tile. */
+__device__ __forceinline__ void ev2_lds_release() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void ev2_lds_acquire() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ void ev2_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -783,7 +805,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
         if (__all(f >= seq)) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      ev2_lds_acquire();
       EV2_MARK(0)
       const int w = tile * EV2_TILE + ln;
       if (ln < EV2_TILE && w < sg.n_windows && !(dbg & 1)) {
@@ -812,7 +834,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
         energies[sg.env_off + w] = sum;
         lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      ev2_lds_release();
       if (ln == 0) flags[8] = seq;
       EV2_MARK(1)
     }
@@ -968,7 +990,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     const double mid = __builtin_fma(mr, mr, mi * mi);
     EV2_MARK(7) /* power */
     while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    ev2_lds_acquire();
     EV2_MARK(6) /* wait for the summing wave */
     double *tg = terms + (4 * wave + g) * EV2_TROW;
 #pragma unroll
@@ -977,7 +999,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       tg[256 - l - 16 * k0] = mir[k0];
     }
     if (l == 0) tg[128] = mid;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ev2_lds_release();
     ev2_wave_sync();
     if (ln == 0) flags[wave] = seq;
   }
