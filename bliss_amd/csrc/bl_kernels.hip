@@ -135,14 +135,58 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pc
   int last = -1;
   const unsigned nvec = (unsigned)sg.n >> 3;
   const uint4 *pv = reinterpret_cast<const uint4 *>(p);
-  for (unsigned v = blockIdx.x * 256u + tid; v < nvec; v += gridDim.x * 256u) {
-    const uint4 q = pv[v];
+  /* Per 16-byte vector (8 samples): sums through v_dot2_i32_i16 (lo + hi and lo^2 + hi^2 per
+   * word; the latter read as unsigned is exact up to 2^31), the histogram through one LDS
+   * atomic per in-range sample.  The first / last non-zero sample can only sit in the first /
+   * last non-zero vector a thread sees (its vectors come in increasing order), so the loop
+   * just remembers those two vectors and the samples are located afterwards.  Two vectors
+   * per iteration keep two loads in flight per lane. */
+  typedef short short2v __attribute__((ext_vector_type(2)));
+  const short2v ones = {1, 1};
+  uint4 fq = make_uint4(0, 0, 0, 0), lq = make_uint4(0, 0, 0, 0);
+  unsigned fv = 0xFFFFFFFFu, lv = 0;
+  bool any = false;
+  auto eat = [&](const uint4 q, unsigned v) {
     const unsigned w[4] = {q.x, q.y, q.z, q.w};
+    int s32 = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-      scan_sample<HIST>(lo, 8u * v + 2u * k, sum, sq, first, last, lh);
-      scan_sample<HIST>(hi, 8u * v + 2u * k + 1u, sum, sq, first, last, lh);
+      short2v pr;
+      __builtin_memcpy(&pr, &w[k], 4);
+      s32 = __builtin_amdgcn_sdot2(pr, ones, s32, false);
+      sq += (unsigned)__builtin_amdgcn_sdot2(pr, pr, 0, false);
+      if (HIST) {
+        const unsigned b0 = (unsigned)((int)(short)(w[k] & 0xFFFFu) + BL_HIST_BINS / 2);
+        const unsigned b1 = (unsigned)((int)(short)(w[k] >> 16) + BL_HIST_BINS / 2);
+        if (b0 < BL_HIST_BINS) atomicAdd(&lh[b0], 1u);
+        if (b1 < BL_HIST_BINS) atomicAdd(&lh[b1], 1u);
+      }
+    }
+    sum += s32;
+    if ((q.x | q.y | q.z | q.w) != 0u) {
+      if (!any) { any = true; fv = v; fq = q; }
+      lv = v; lq = q;
+    }
+  };
+  const unsigned gstride = gridDim.x * 256u;
+  unsigned v = blockIdx.x * 256u + tid;
+  for (; v + gstride < nvec; v += 2 * gstride) {
+    const uint4 q0 = pv[v], q1 = pv[v + gstride];
+    eat(q0, v);
+    eat(q1, v + gstride);
+  }
+  if (v < nvec) eat(pv[v], v);
+  if (any) {
+    const unsigned fw[4] = {fq.x, fq.y, fq.z, fq.w}, lw[4] = {lq.x, lq.y, lq.z, lq.w};
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      if (fw[k] >> 16) first = 8u * fv + 2u * k + 1u;
+      if (fw[k] & 0xFFFFu) first = 8u * fv + 2u * k;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (lw[k] & 0xFFFFu) last = (int)(8u * lv + 2u * k);
+      if (lw[k] >> 16) last = (int)(8u * lv + 2u * k + 1u);
     }
   }
   if (blockIdx.x == 0 && tid < (sg.n & 7)) {
