@@ -423,6 +423,24 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
    * batch: within a chunk each 16-lane group adds its frames in frame order, the 16
    * groups are folded in group order, k_freq_finish adds the chunks in chunk order. */
   const int parts = (sg.n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
+  /* one frame ahead: 16 unconditional loads per lane (frame index clamped into the song,
+   * an inactive frame is zeroed when it is consumed), so the HBM latency of frame f+1
+   * hides behind the transform of frame f */
+  uint2 pre[16];
+  const bool stereo = sg.channels == 2;
+  auto fetch = [&](int f_) {
+    const int fc = min(f_, sg.n_frames - 1);
+    if (stereo) {
+      const uint2 *q = reinterpret_cast<const uint2 *>(p + (size_t)fc * 1024);
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) pre[m1] = q[16 * m1 + l];
+    } else {
+      const unsigned *q = reinterpret_cast<const unsigned *>(p + (size_t)fc * 512);
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) pre[m1] = make_uint2(q[16 * m1 + l], 0u);
+    }
+  };
+  fetch(blockIdx.x * BL_FREQ_CHUNK + g);
   for (int chunk = blockIdx.x; chunk < parts; chunk += gridDim.x) {
     float a_own[8], a_mir[8], a_mid = 0.f;
 #pragma unroll
@@ -431,46 +449,33 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
       const int f = chunk * BL_FREQ_CHUNK + it * 16 + g;
       const bool active = f < sg.n_frames;
       float re[16], im[16];
-      if (active && sg.channels == 2) {
-        /* ref :69-75: (float)((L + R) / 2) * hann[d], integer average truncates */
-        const uint2 *q = reinterpret_cast<const uint2 *>(p + (size_t)f * 1024);
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) {
-          const uint2 w = q[16 * m1 + l];
-          const int d = 32 * m1 + 2 * l;
-          const int a0 = (int)(short)(w.x & 0xFFFFu), a1 = (int)(short)(w.x >> 16);
-          const int a2 = (int)(short)(w.y & 0xFFFFu), a3 = (int)(short)(w.y >> 16);
-          if (SCAN) {
+      for (int m1 = 0; m1 < 16; ++m1) {
+        const uint2 w = pre[m1];
+        const int d = 32 * m1 + 2 * l;
+        const int a0 = (int)(short)(w.x & 0xFFFFu), a1 = (int)(short)(w.x >> 16);
+        const int a2 = (int)(short)(w.y & 0xFFFFu), a3 = (int)(short)(w.y >> 16);
+        if (SCAN && active) {
+          if (stereo) {
             const unsigned i0 = (unsigned)f * 1024u + 2u * (unsigned)d;
             scan_sample(a0, i0, ssum, ssq, sfirst, slast, lh);
             scan_sample(a1, i0 + 1u, ssum, ssq, sfirst, slast, lh);
             scan_sample(a2, i0 + 2u, ssum, ssq, sfirst, slast, lh);
             scan_sample(a3, i0 + 3u, ssum, ssq, sfirst, slast, lh);
-          }
-          const int s0 = (a0 + a1) / 2;
-          const int s1 = (a2 + a3) / 2;
-          re[m1] = (float)s0 * hann[d];
-          im[m1] = (float)s1 * hann[d + 1];
-        }
-      } else if (active) { /* ref :76-80 */
-        const unsigned *q = reinterpret_cast<const unsigned *>(p + (size_t)f * 512);
-#pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) {
-          const unsigned w = q[16 * m1 + l];
-          const int d = 32 * m1 + 2 * l;
-          const int a0 = (int)(short)(w & 0xFFFFu), a1 = (int)(short)(w >> 16);
-          if (SCAN) {
+          } else {
             const unsigned i0 = (unsigned)f * 512u + (unsigned)d;
             scan_sample(a0, i0, ssum, ssq, sfirst, slast, lh);
             scan_sample(a1, i0 + 1u, ssum, ssq, sfirst, slast, lh);
           }
-          re[m1] = (float)a0 * hann[d];
-          im[m1] = (float)a1 * hann[d + 1];
         }
-      } else {
-#pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) { re[m1] = 0.f; im[m1] = 0.f; }
+        /* stereo, ref :69-75: (float)((L + R) / 2) * hann[d], the integer average truncates;
+         * mono, ref :76-80: (float)s * hann[d] */
+        const int s0 = stereo ? (a0 + a1) / 2 : a0;
+        const int s1 = stereo ? (a2 + a3) / 2 : a1;
+        re[m1] = active ? (float)s0 * hann[d] : 0.f;
+        im[m1] = active ? (float)s1 * hann[d + 1] : 0.f;
       }
+      fetch(it + 1 < BL_FREQ_CHUNK / 16 ? f + 16 : (chunk + (int)gridDim.x) * BL_FREQ_CHUNK + g);
       /* the exchange buffers of a 16-lane group are private to it, hence to its wave: no
        * workgroup barrier inside the frame loop, the four waves drift apart freely */
       bl_fft512_phaseA<float>(l, re, im, tw256, gx);
