@@ -125,19 +125,28 @@ BL_HD void bl_fft512_phaseA(int n0, T (&re)[16], T (&im)[16], const bl_c2<T> *tw
  * half row (k0 = 8..15) for the partner lane.
  */
 template <typename T>
-BL_HD void bl_fft512_phaseB(int k1, T (&re)[16], T (&im)[16], const bl_c2<T> *xch,
-                            bl_c2<T> *par) {
+BL_HD void bl_fft512_phaseB_load(int k1, T (&re)[16], T (&im)[16], const bl_c2<T> *xch) {
 #pragma unroll
   for (int n0 = 0; n0 < 16; ++n0) {
     bl_c2<T> v = xch[k1 * 17 + n0];
     re[n0] = v.re; im[n0] = v.im;
   }
+}
+/* second half of phase B; with a barrier after the load half, `par` may alias `xch` */
+template <typename T>
+BL_HD void bl_fft512_phaseB_publish(int k1, T (&re)[16], T (&im)[16], bl_c2<T> *par) {
   bl_fft16(re, im);
 #pragma unroll
   for (int k0 = 8; k0 < 16; ++k0) {
     bl_c2<T> v; v.re = re[bl_pos16(k0)]; v.im = im[bl_pos16(k0)];
     par[k1 * 8 + (k0 - 8)] = v;
   }
+}
+template <typename T>
+BL_HD void bl_fft512_phaseB(int k1, T (&re)[16], T (&im)[16], const bl_c2<T> *xch,
+                            bl_c2<T> *par) {
+  bl_fft512_phaseB_load<T>(k1, re, im, xch);
+  bl_fft512_phaseB_publish<T>(k1, re, im, par);
 }
 
 /*

@@ -383,8 +383,10 @@ struct bl_tables {
 };
 
 #define BL_FREQ_CHUNK 256 /* frames per partial spectrum */
-#define BL_FREQ_LDS_BYTES                                                              \
-  (16 * BL_FFT_XCH_ELEMS * 8 + 16 * BL_FFT_PAR_ELEMS * 8 + 2 * 256 * 8 + 512 * 4 + BL_HIST_BINS * 4)
+/* exchange buffers (the partner half rows reuse them), twiddles, Hann; + histogram when
+ * the scan is fused.  40.8 KB -> three workgroups per CU (the kernel needs 158 VGPRs) */
+#define BL_FREQ_LDS_BYTES(scan)                                                        \
+  (16 * BL_FFT_XCH_ELEMS * 8 + 2 * 256 * 8 + 512 * 4 + ((scan) ? BL_HIST_BINS * 4 : 0))
 
 /* SCAN = true fuses k_pcm_scan's statistics into the same pass over the PCM (the frames
  * cover every sample except a tail shorter than one frame, which the block that owns the
@@ -396,8 +398,7 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
                                                      unsigned *hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c2f *xch = reinterpret_cast<c2f *>(smem);                       /* 16 x 272 */
-  c2f *par = xch + 16 * BL_FFT_XCH_ELEMS;                         /* 16 x 128 */
-  c2f *tw256 = par + 16 * BL_FFT_PAR_ELEMS;
+  c2f *tw256 = xch + 16 * BL_FFT_XCH_ELEMS;
   c2f *tw512 = tw256 + 256;
   float *hann = reinterpret_cast<float *>(tw512 + 256);
   unsigned *lh = reinterpret_cast<unsigned *>(hann + 512);        /* SCAN: 4096-bin histogram */
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
   unsigned sfirst = 0xFFFFFFFFu;
   int slast = -1;
 
-  c2f *gx = xch + g * BL_FFT_XCH_ELEMS, *gp = par + g * BL_FFT_PAR_ELEMS;
+  c2f *gx = xch + g * BL_FFT_XCH_ELEMS, *gp = gx; /* partner rows alias the transpose */
   float *red = reinterpret_cast<float *>(smem); /* [16][256], aliases xch */
   /* The frames of a song are cut into fixed chunks of BL_FREQ_CHUNK (independent of
    * the launch geometry), so a song's result never depends on what else is in the
@@ -480,7 +481,9 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
        * workgroup barrier inside the frame loop, the four waves drift apart freely */
       bl_fft512_phaseA<float>(l, re, im, tw256, gx);
       bl_wave_sync();
-      bl_fft512_phaseB<float>(l, re, im, gx, gp);
+      bl_fft512_phaseB_load<float>(l, re, im, gx);
+      bl_wave_sync();
+      bl_fft512_phaseB_publish<float>(l, re, im, gp);
       bl_wave_sync();
       float own[8], mir[8], mid;
       bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
@@ -1405,9 +1408,11 @@ int init_locked(int device) {
     g.fuse_scan = f && f[0] == '1';
   }
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   BL_FREQ_LDS_BYTES(false)));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   BL_FREQ_LDS_BYTES(true)));
   if (!g.side_ok) {
     BL_HIP_CHECK(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
     BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_env, hipEventDisableTiming));
@@ -1551,7 +1556,7 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   const bool fused = (what & 2) != 0 && g.fuse_scan;
   if (fused) {
     ProfScope ps(PK_FREQ, stream);
-    hipLaunchKernelGGL(k_freq_frames<true>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES,
+    hipLaunchKernelGGL(k_freq_frames<true>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES(true),
                        stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
   } else {
     ProfScope ps(PK_SCAN, stream);
@@ -1607,7 +1612,7 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   if (what & 2) {
     if (!fused) {
       ProfScope ps(PK_FREQ, stream);
-      hipLaunchKernelGGL(k_freq_frames<false>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES,
+      hipLaunchKernelGGL(k_freq_frames<false>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES(false),
                          stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
     }
     ProfScope ps(PK_FREQ_FIN, stream);
