@@ -205,11 +205,13 @@ def main():
             # profile (profiles/*_hbm_traffic.json, corrected as MI355X_MICROARCH.md prescribes),
             # scaled from its per-song figure to this launch's song count; None if absent
             traffic = None
+            valu_busy = lds_busy = None   # SQ counters of the same committed profile, if collected
             try:
                 import glob
                 tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
-                traffic = tj["kernels"]["k_env_windows2"]["hbm_bytes_per_song"] * songs * \
-                    (song_samples / 15876000.0)
+                tk = tj["kernels"]["k_env_windows2"]
+                traffic = tk["hbm_bytes_per_song"] * songs * (song_samples / 15876000.0)
+                valu_busy, lds_busy = tk.get("valu_busy_frac"), tk.get("lds_busy_frac")
             except Exception:
                 pass
             roof = {"bound": "hbm", "kernel": "k_env_windows2", "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -221,7 +223,9 @@ def main():
                     "algorithmic_bytes_per_launch": launch_bytes,
                     "secondary_f64_valu": {"achieved_Tinstr_per_s": f64_rate,
                                            "peak_Tinstr_per_s": FP64_VALU_PEAK_TFLOPS / 2,
-                                           "frac": f64_rate / (FP64_VALU_PEAK_TFLOPS / 2)}}
+                                           "frac": f64_rate / (FP64_VALU_PEAK_TFLOPS / 2),
+                                           "valu_busy_frac_profiled": valu_busy,
+                                           "lds_busy_frac_profiled": lds_busy}}
         whole_path_gbs = value / world * alg_bytes_song / 1e9
 
         # BASELINE config 4: standalone 10 000 x 10 000 bl_distance matrix on one GPU
