@@ -578,12 +578,7 @@ __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ p
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_env_windows                                                              */
-
-#define BL_TILE_W 16                      /* windows per tile (one per 16-lane group) */
-#define BL_TILE_X (BL_TILE_W * 256 + 256) /* 4352 samples feed one tile */
-#define BL_ENV_R1_BYTES (2 * BL_TILE_X * 8) /* x + z, later xch, later par + terms */
-#define BL_ENV_LDS_BYTES (BL_ENV_R1_BYTES + 16 * 8 + BL_TILE_W * 16 * 8 + 2 * 256 * 16)
+/* envelope windows: shared arithmetic                                        */
 
 /* ref tempo_atk_sort.c:109-114 for one sample: RN(((s/2^15) - (mean/2^15)) / vd).
  * k = s - mean is exact, q0 = k*rcp is within 2 ulp of k/vprime, the remainder
@@ -612,142 +607,13 @@ __device__ __forceinline__ double bl_norm(int k, double vprime, double rcp) {
     y_;                                                             \
   })
 
-__global__ __launch_bounds__(256) void k_env_windows(const int16_t *__restrict__ pcm,
-                                                     const bl_dsong *__restrict__ songs,
-                                                     const bl_dstats *__restrict__ stats,
-                                                     bl_tables tb, float *energies, double *lc) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  /* region R1, three lives per tile */
-  double *xs = reinterpret_cast<double *>(smem);          /* [16 + 4352] normalised x  */
-  double *zs = xs + 16 + BL_TILE_X;                        /* [4352 - 16] FIR output z  */
-  c2d *xch = reinterpret_cast<c2d *>(smem);                /* 16 x 272                  */
-  c2d *par = reinterpret_cast<c2d *>(smem);                /* 16 x 128                  */
-  double *terms = reinterpret_cast<double *>(smem + 16 * BL_FFT_PAR_ELEMS * 16); /* [16][257] */
-  /* persistent */
-  double *heads = reinterpret_cast<double *>(smem + BL_ENV_R1_BYTES + 16 * 8); /* [16][16] */
-  c2d *tw256 = reinterpret_cast<c2d *>(heads + BL_TILE_W * 16);
-  c2d *tw512 = tw256 + 256;
-
-  const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-  const bl_dsong sg = songs[blockIdx.y];
-  const bl_dstats st = stats[blockIdx.y];
-  const int16_t *p = pcm + sg.pcm_off;
-  const int mean = st.mean;
-  const double vprime = st.vprime, rcp = st.rcp;
-  tw256[tid] = tb.tw256_d[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout */
-  tw512[tid] = tb.tw512_d[tid];
-  if (tid < 16) xs[tid] = 0.0; /* never-used left margin of the FIR registers */
-  const int n_tiles = (sg.n_windows + BL_TILE_W - 1) / BL_TILE_W;
-  const int n_used = 256 * (sg.n_windows + 1); /* samples any window reads */
-
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int w0 = tile * BL_TILE_W;
-    const int s0 = w0 * 256; /* first sample of the tile */
-    __syncthreads();         /* previous tile's LDS reads are done */
-    /* 1. PCM -> normalised f64 in LDS (8 samples = 16 bytes per load) */
-    for (int c = tid; c < BL_TILE_X / 8; c += 256) {
-      const int i0 = s0 + 8 * c;
-      uint4 q = make_uint4(0, 0, 0, 0);
-      if (i0 + 8 <= n_used) q = *reinterpret_cast<const uint4 *>(p + i0);
-      const unsigned w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-        xs[16 + 8 * c + 2 * k] = bl_norm(lo - mean, vprime, rcp);
-        xs[16 + 8 * c + 2 * k + 1] = bl_norm(hi - mean, vprime, rcp);
-      }
-    }
-    __syncthreads();
-    /* 2a. steady-state FIR: z[j] for the 17 tile-local outputs 17*tid .. 17*tid+16
-     *     (ref :123-138 with a full delay line; identical to the per-window
-     *     zero-state filter for every output >= 16 samples into its window) */
-    {
-      double r[33];
-      const double *xb = xs + 17 * tid; /* xs[16 + jl - 16 + i] */
-#pragma unroll
-      for (int i = 0; i < 33; ++i) r[i] = xb[i];
-#pragma unroll
-      for (int i = 0; i < 17; ++i) {
-#define XR(m) r[i + 16 - (m)]
-        const double y = BL_FIR(XR);
-#undef XR
-        const int jl = 17 * tid + i;
-        if (jl >= 16) zs[jl - 16] = y;
-      }
-    }
-    /* 2b. first 16 outputs of each window: delay line starts from zero (ref :121) */
-    {
-      const double *xw = xs + 16 + 256 * g; /* window g of the tile */
-#define XH(m) ((l - (m)) >= 0 ? xw[l - (m)] : 0.0)
-      heads[g * 16 + l] = BL_FIR(XH);
-#undef XH
-    }
-    __syncthreads();
-    /* 3. FFT input: lane l of group g holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
-    double re[16], im[16];
-    {
-      const double *zw = zs + 256 * g - 16; /* zw[n] = z of window sample n (n >= 16) */
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) {
-        const int nn = 32 * m1 + 2 * l;
-        if (m1 == 0 && l < 8) {
-          re[m1] = heads[g * 16 + nn];
-          im[m1] = heads[g * 16 + nn + 1];
-        } else {
-          re[m1] = zw[nn];
-          im[m1] = zw[nn + 1];
-        }
-      }
-    }
-    __syncthreads(); /* x / z dead, region becomes the transpose buffer */
-    c2d *gx = xch + g * BL_FFT_XCH_ELEMS;
-    bl_fft512_phaseA<double>(l, re, im, tw256, gx);
-    __syncthreads();
-#pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) {
-      const c2d v = gx[l * 17 + n0];
-      re[n0] = v.re; im[n0] = v.im;
-    }
-    __syncthreads(); /* transpose buffer dead, region becomes par + terms */
-    bl_fft16(re, im);
-    c2d *gp = par + g * BL_FFT_PAR_ELEMS;
-#pragma unroll
-    for (int k0 = 8; k0 < 16; ++k0) {
-      c2d v; v.re = re[bl_pos16(k0)]; v.im = im[bl_pos16(k0)];
-      gp[l * 8 + (k0 - 8)] = v;
-    }
-    __syncthreads();
-    {
-      double own[8], mir[8], mid;
-      bl_fft512_phaseC<double>(l, re, im, tw512, gp, own, mir, mid);
-      double *tg = terms + g * 257;
-#pragma unroll
-      for (int k0 = 0; k0 < 8; ++k0) {
-        tg[l + 16 * k0] = own[k0];
-        tg[256 - l - 16 * k0] = mir[k0];
-      }
-      if (l == 0) tg[128] = mid;
-    }
-    __syncthreads();
-    /* 4. ref :142-151: float sum_fft += (double)|X_k|^2, k = 0..256 in order,
-     *    rounded to f32 after every add */
-    if (tid < BL_TILE_W && w0 + tid < sg.n_windows) {
-      const double *tg = terms + tid * 257;
-      float sum = 0.f;
-      for (int k = 0; k <= 256; ++k) sum = (float)((double)sum + tg[k]);
-      energies[sg.env_off + w0 + tid] = sum;
-      lc[sg.env_off + w0 + tid] = bl_tail_compress((double)sum, tb.log101);
-    }
-  }
-}
-
 /* ------------------------------------------------------------------------- */
-/* k_env_windows2: same arithmetic, wave-autonomous pipeline                  */
+/* k_env_windows2: normalise + FIR + DFT + ordered sum, wave-autonomous      */
 /*
  * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, so the
  * ~200 VGPRs the unrolled FIR/DFT code wants fit without spilling), no workgroup barrier
  * inside the loop.  A compute wave owns 4 consecutive windows per round (one per
- * 16-lane group) and does everything for them out of its private 11.4 KB LDS slice:
+ * 16-lane group) and does everything for them out of its private 11.9 KB LDS slice:
  * normalise 1280 samples once, 17-tap FIR (20 outputs per lane from 36 register-held
  * inputs, written back in place), the four 512-point f64 DFTs with split re/im
  * exchanges, and the 4 x 257 power terms.  The f32-rounded, strictly ordered sum of
@@ -801,8 +667,8 @@ __device__ __forceinline__ void ev2_wave_sync() {
 }
 
 /* DBG = true adds the measurement aids of BL_AMD_ENV_DBG (bit 0: skip the ordered sums,
- * bit 1: skip the compute, bit 2: clock probe, bit 3: per-phase cycle counts); the
- * production instantiation carries none of it (device printf alone costs registers). */
+ * bit 1: skip the compute, bit 2: clock probe); the production instantiation carries none
+ * of it (device printf alone costs registers). */
 template <bool DBG>
 __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
@@ -833,16 +699,6 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   const int n_tiles = (sg.n_windows + EV2_TILE - 1) / EV2_TILE;
   const int n_used = 256 * (sg.n_windows + 1);
   int seq = 0;
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long ph_t = 0;
-#define EV2_MARK(i)                                                     \
-  if (DBG && (dbg & 8)) {                                               \
-    __builtin_amdgcn_sched_barrier(0);                                  \
-    const long long now_ = (long long)__builtin_amdgcn_s_memtime();     \
-    ph[i] += now_ - ph_t;                                               \
-    ph_t = now_;                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                  \
-  }
   const long long dbg_c0 = (DBG && (dbg & 4)) ? (long long)__builtin_amdgcn_s_memtime() : 0;
   const long long dbg_w0 = (DBG && (dbg & 4)) ? (long long)wall_clock64() : 0;
 
@@ -851,14 +707,12 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     __builtin_amdgcn_s_setprio(3);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       ++seq;
-      if (DBG && (dbg & 8)) ph_t = (long long)__builtin_amdgcn_s_memtime();
       for (;;) {
         const int f = ln < EV2_CWAVES ? flags[ln] : seq;
         if (__all(f >= seq)) break;
         __builtin_amdgcn_s_sleep(1);
       }
       ev2_lds_acquire();
-      EV2_MARK(0)
       const int w = tile * EV2_TILE + ln;
       if (ln < EV2_TILE && w < sg.n_windows && !(dbg & 1)) {
         /* ref :142-151: float sum_fft += (double)|X_k|^2 for k = 0..256 in order */
@@ -888,12 +742,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       }
       ev2_lds_release();
       if (ln == 0) flags[8] = seq;
-      EV2_MARK(1)
     }
-    if constexpr (DBG)
-    if ((dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && ln == 0)
-      printf("ev2 summing wave (cycles/tile): wait for terms %lld  chain+store %lld\n", ph[0] / n_tiles,
-             ph[1] / n_tiles);
     return;
   }
 
@@ -936,7 +785,6 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       if (ln == 0) flags[wave] = seq;
       continue;
     }
-    if (DBG && (dbg & 8)) ph_t = (long long)__builtin_amdgcn_s_memtime();
     /* 1. normalise (ref :109-114) straight into registers: r[16..35] = own 20 samples,
      *    r[0..15] = the previous lane's last 16 (DPP wave shift, no LDS round trip) */
     double yv[20], yh;
@@ -979,7 +827,6 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       yh = BL_FIR(XH);
 #undef XH
     }
-    EV2_MARK(0) /* normalise + FIR */
     ev2_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
 #pragma unroll
     for (int i = 0; i < 20; ++i) buf[22 * ln + 18 + i] = yv[i];
@@ -997,9 +844,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       im[m1] = buf[s + 1];
     }
     ev2_wave_sync(); /* window data is in registers; the slice becomes exchange space */
-    EV2_MARK(1) /* z store + DFT input load */
     bl_fft512_pass1<double>(l, re, im, tw256);
-    EV2_MARK(2) /* pass 1 */
     /* transposes: rows of 18 doubles so that a lane reads its row as 8 aligned 16-byte
      * loads (ds_read_b128: 4 LDS cycles; the ds_read2_b64 hipcc picks for unaligned pairs
      * costs 16).  Layouts checked with tools/lds_model.py: conflict-free. */
@@ -1017,9 +862,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
     ev2_wave_sync();
-    EV2_MARK(3) /* transposes */
     bl_fft16(re, im);
-    EV2_MARK(4) /* pass 2 */
     /* partner half rows (k0 = 8..15) as (re, im) pairs, 9 pairs per lane row */
     double2 *pg = reinterpret_cast<double2 *>(buf) + g * 144;
 #pragma unroll
@@ -1040,10 +883,8 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     }
     const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
     const double mid = __builtin_fma(mr, mr, mi * mi);
-    EV2_MARK(7) /* power */
     while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
     ev2_lds_acquire();
-    EV2_MARK(6) /* wait for the summing wave */
     double *tg = terms + (4 * wave + g) * EV2_TROW;
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
@@ -1055,12 +896,6 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     ev2_wave_sync();
     if (ln == 0) flags[wave] = seq;
   }
-  if constexpr (DBG)
-  if ((dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && ln == 0 && (wave == 0 || wave == 3))
-    printf("ev2 phases wave %d (cycles/round): fir %lld  zld %lld  pass1 %lld  xch %lld  pass2 %lld  par %lld  "
-           "wait %lld  power %lld\n", wave, ph[0] / n_tiles, ph[1] / n_tiles, ph[2] / n_tiles,
-           ph[3] / n_tiles, ph[4] / n_tiles, ph[5] / n_tiles, ph[6] / n_tiles, ph[7] / n_tiles);
-  if constexpr (DBG)
   if ((dbg & 4) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     const long long c = (long long)__builtin_amdgcn_s_memtime() - dbg_c0;
     const long long w = (long long)wall_clock64() - dbg_w0;
@@ -1310,7 +1145,6 @@ struct Buf {
 struct Ctx {
   std::mutex mu;
   bool ready = false;
-  bool env_v1 = false;
   int env_dbg = 0;
   bool fuse_scan = false;
   hipStream_t side = nullptr; /* envelope tail runs here, beside the frequency pass */
@@ -1393,15 +1227,11 @@ int init_locked(int device) {
   g.tb.tw512_f = g.tb.tw256_f + 256;
   g.tb.hann = reinterpret_cast<const float *>(g.tb.tw512_f + 256);
   g.tb.log101 = log((double)(1 + 100.0f)); /* ref tempo_atk_sort.c:188, log(1 + mu) */
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_ENV_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   {
-    const char *v = getenv("BL_AMD_ENV_V1"); /* A/B switch for measurements only */
-    g.env_v1 = v && v[0] == '1';
     const char *d = getenv("BL_AMD_ENV_DBG"); /* bit 0: skip the ordered sums, bit 1: skip compute */
     g.env_dbg = d ? atoi(d) : 0;
     const char *f = getenv("BL_AMD_FUSE_SCAN");
@@ -1525,7 +1355,6 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   const int max_frames = (max_n / 512);
   const int gx_scan = grid_x_for(((long long)max_n / 8 + 255) / 256, n_songs, 8);
   const int gx_freq = grid_x_for((max_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK, n_songs, 6);
-  const int gx_env = grid_x_for((2 * max_frames + BL_TILE_W - 1) / BL_TILE_W, n_songs, 6);
 
   if (ensure(g.songs, sizeof(bl_dsong) * n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.stats, sizeof(bl_dstats) * n_songs) != BL_OK) return BL_UNEXPECTED;
@@ -1580,20 +1409,15 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   if (what & 4) {
     {
       ProfScope ps(PK_ENV, stream);
-      if (g.env_v1) {
-        hipLaunchKernelGGL(k_env_windows, dim3(gx_env, n_songs), dim3(256), BL_ENV_LDS_BYTES, stream,
-                           d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc);
-      } else {
-        /* one 512-thread workgroup per CU; blocks of a song split its 28-window tiles */
-        const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2);
-        if (g.env_dbg)
-          hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                             EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc,
-                             g.env_dbg);
-        else
-          hipLaunchKernelGGL(k_env_windows2<false>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                             EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc, 0);
-      }
+      /* one 512-thread workgroup per CU; blocks of a song split its 28-window tiles */
+      const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2);
+      if (g.env_dbg)
+        hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                           EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc,
+                           g.env_dbg);
+      else
+        hipLaunchKernelGGL(k_env_windows2<false>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                           EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc, 0);
     }
     hipStream_t ts = stream;
     if ((what & 3) && g.side_ok) { /* something to overlap with */
