@@ -1433,6 +1433,15 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
     }
     if (tail_async) BL_HIP_CHECK(hipEventRecord(g.ev_tail, g.side));
   }
+  /* The short amplitude kernel goes before the wide frequency pass: the tail's 54 KB
+   * workgroups only reach a CU when the dispatcher has no pending frequency workgroup to put
+   * there, so they have to be resident before that pass begins (launched after it, the tail
+   * started ~60 ms late and ~10 ms of it were exposed per 8 192 songs). */
+  if (what & 1) {
+    ProfScope ps(PK_AMP, stream);
+    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, d_songs, d_stats, d_hist,
+                       d_results);
+  }
   if (what & 2) {
     if (!fused) {
       ProfScope ps(PK_FREQ, stream);
@@ -1441,11 +1450,6 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
     }
     ProfScope ps(PK_FREQ_FIN, stream);
     hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, d_songs,
-                       d_results);
-  }
-  if (what & 1) {
-    ProfScope ps(PK_AMP, stream);
-    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, d_songs, d_stats, d_hist,
                        d_results);
   }
   if (tail_async) BL_HIP_CHECK(hipStreamWaitEvent(stream, g.ev_tail, 0));
