@@ -312,3 +312,25 @@ def test_extreme_amplitudes(gpu_lib, oracle):
         for k in FLOATS:
             a, b = float(got[i][k]), float(ref[k])
             assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= REL * max(abs(b), 1e-6), (i, k, a, b)
+
+
+def test_random_soak_small(gpu_lib, oracle):
+    """tools/soak.py on 24 random songs (random rate / channels / level / spectrum / DC / silences): integers
+    exact, floats within 1e-5 + 1e-4 |ref| (ref tests/test_analyze.c:30-35 uses 1e-5 absolute)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import soak
+    songs = [soak.make_song(9000 + i, 12.0) for i in range(24)]
+    corpus = bliss_amd.DeviceCorpus([p.size for p, _, _ in songs], [c for _, c, _ in songs],
+                                    [d for _, _, d in songs])
+    for i, (p, _, _) in enumerate(songs):
+        corpus.upload(i, p)
+    corpus.analyze()
+    got = corpus.fetch()
+    for i, (p, c, d) in enumerate(songs):
+        ref = oracle.analyze(p, c, d)
+        for k in INTS:
+            assert int(got[i][k]) == int(ref[k]), (i, k, int(got[i][k]), int(ref[k]))
+        for k in FLOATS:
+            a, b = float(got[i][k]), float(ref[k])
+            assert abs(a - b) <= 1e-5 + REL * abs(b), (i, k, a, b)
