@@ -1013,25 +1013,34 @@ __device__ __forceinline__ float bl_cos(const float4 a, const float4 b) {
   return (float)((double)dot / (sqrt((double)na) * sqrt((double)nb)));
 }
 
+/* A workgroup owns BL_PW_ROWS rows x 1024 columns: every thread keeps its four column
+ * vectors in registers and walks down the rows (the row vector is wave-uniform: scalar
+ * loads), so a vector is fetched once per 16 outputs instead of once per output and the
+ * index arithmetic is paid once.  Output: 16-byte stores, each row segment contiguous. */
+#define BL_PW_ROWS 16
 template <bool COSINE>
 __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vecs, int n,
-                                                  int row_begin, float *__restrict__ out) {
-  const int row = blockIdx.y;
-  const float4 a = vecs[row_begin + row];
-  float *orow = out + (size_t)row * n;
+                                                  int row_begin, int n_rows,
+                                                  float *__restrict__ out) {
   const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (j0 >= n) return;
-  float r[4];
+  float4 b[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int j = min(j0 + k, n - 1);
-    const float4 b = vecs[j];
-    r[k] = COSINE ? bl_cos(a, b) : bl_dist(a, b);
-  }
-  if (j0 + 4 <= n && ((reinterpret_cast<size_t>(orow + j0) & 15) == 0)) {
-    *reinterpret_cast<float4 *>(orow + j0) = make_float4(r[0], r[1], r[2], r[3]);
-  } else {
-    for (int k = 0; k < 4 && j0 + k < n; ++k) orow[j0 + k] = r[k];
+  for (int k = 0; k < 4; ++k) b[k] = vecs[min(j0 + k, n - 1)];
+  const int r0 = blockIdx.y * BL_PW_ROWS;
+  const int r1 = min(r0 + BL_PW_ROWS, n_rows);
+  const bool vec_ok = j0 + 4 <= n && (n & 3) == 0 && ((reinterpret_cast<size_t>(out) & 15) == 0);
+  for (int row = r0; row < r1; ++row) {
+    const float4 a = vecs[row_begin + row];
+    float *orow = out + (size_t)row * n;
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = COSINE ? bl_cos(a, b[k]) : bl_dist(a, b[k]);
+    if (vec_ok) {
+      *reinterpret_cast<float4 *>(orow + j0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+      for (int k = 0; k < 4 && j0 + k < n; ++k) orow[j0 + k] = r[k];
+    }
   }
 }
 
@@ -1562,14 +1571,16 @@ static int matrix_device(const struct force_vector_s *d_vecs, int n, int row_beg
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float4 *v = reinterpret_cast<const float4 *>(d_vecs);
   const int gx = (n + 1023) / 1024;
-  for (int r0 = 0; r0 < n_rows; r0 += 65535) {
-    const int cnt = n_rows - r0 < 65535 ? n_rows - r0 : 65535;
+  const int chunk = 65535 * BL_PW_ROWS; /* rows per launch (gridDim.y limit) */
+  for (int r0 = 0; r0 < n_rows; r0 += chunk) {
+    const int cnt = n_rows - r0 < chunk ? n_rows - r0 : chunk;
+    const int gy = (cnt + BL_PW_ROWS - 1) / BL_PW_ROWS;
     ProfScope ps(PK_DIST, s);
     if (cosine)
-      hipLaunchKernelGGL(k_pairwise<true>, dim3(gx, cnt), dim3(256), 0, s, v, n, row_begin + r0,
+      hipLaunchKernelGGL(k_pairwise<true>, dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
     else
-      hipLaunchKernelGGL(k_pairwise<false>, dim3(gx, cnt), dim3(256), 0, s, v, n, row_begin + r0,
+      hipLaunchKernelGGL(k_pairwise<false>, dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
   }
   BL_HIP_CHECK(hipGetLastError());
