@@ -32,6 +32,7 @@
 #include <string.h>
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "bl_device.h"
@@ -1670,8 +1671,10 @@ int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samp
   if (ensure(g.results, sizeof(bl_amd_song_result) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
   bl_amd_song_result *d_res = static_cast<bl_amd_song_result *>(g.results.p);
 
-  /* waves of songs of at most WAVE_BYTES of PCM each (one song may exceed it) */
-  const size_t WAVE_BYTES = (size_t)256 << 20;
+  /* waves of songs of at most WAVE_BYTES of PCM each (one song may exceed it): large enough
+   * that the ~20 ms latency of the serial envelope tail (paid once per wave) stays below
+   * the wave's transfer time, small enough for two pinned and two device buffers */
+  const size_t WAVE_BYTES = (size_t)2 << 30;
   int begin = 0, wave = 0;
   int rc = BL_OK;
   /* the shared scratch (stats, histograms, ...) is per launch group, so waves
@@ -1706,10 +1709,20 @@ int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samp
     }
     if (ensure(g.arena[k], bytes) != BL_OK) { rc = BL_UNEXPECTED; break; }
     int16_t *stage = static_cast<int16_t *>(g.pinned[k]);
-    for (size_t i = 0; i < desc.size(); ++i) {
-      memcpy(stage + desc[i].pcm_offset, h_pcm[begin + i], (size_t)desc[i].n_samples * 2);
-      const size_t padded = ((size_t)desc[i].n_samples + 7) & ~(size_t)7;
-      for (size_t z = desc[i].n_samples; z < padded; ++z) stage[desc[i].pcm_offset + z] = 0;
+    {
+      /* staging copy on several host threads: one thread moves ~10 GB/s, the link takes 50+ */
+      const int n_thr = (int)std::min<size_t>(8, std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
+      auto copy_range = [&](int t) {
+        for (size_t i = (size_t)t; i < desc.size(); i += (size_t)n_thr) {
+          memcpy(stage + desc[i].pcm_offset, h_pcm[begin + i], (size_t)desc[i].n_samples * 2);
+          const size_t padded = ((size_t)desc[i].n_samples + 7) & ~(size_t)7;
+          for (size_t z = desc[i].n_samples; z < padded; ++z) stage[desc[i].pcm_offset + z] = 0;
+        }
+      };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < n_thr; ++t) pool.emplace_back(copy_range, t);
+      copy_range(0);
+      for (auto &th : pool) th.join();
     }
     hipStream_t s = g.streams[k];
     if (hipMemcpyAsync(g.arena[k].p, stage, elems * 2, hipMemcpyHostToDevice, s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
