@@ -334,3 +334,27 @@ def test_random_soak_small(gpu_lib, oracle):
         for k in FLOATS:
             a, b = float(got[i][k]), float(ref[k])
             assert abs(a - b) <= 1e-5 + REL * abs(b), (i, k, a, b)
+
+
+def test_invalid_inputs_are_rejected(gpu_lib, tmp_path):
+    """Inputs the reference leaves undefined fail loudly instead of reading out of bounds: too short
+    (nSamples < 5120: ref src/tempo_atk_sort.c:63-67 would run -2 windows), channel counts other than
+    1 / 2, duration 0 (division, ref :283), a truncated or non-audio file."""
+    good = np.ones(8192, dtype=np.int16)
+    for pcm, ch, dur in ((good[:5119], 1, 1), (good, 3, 1), (good, 0, 1), (good, 2, 0)):
+        with pytest.raises(RuntimeError):
+            bliss_amd.analyze_batch_host([pcm], ch, dur)
+    song = _lib.BlSong()
+    junk = tmp_path / "junk.flac"
+    junk.write_bytes(b"fLaC" + bytes(range(200)))
+    assert gpu_lib.bl_analyze(str(junk).encode(), C.byref(song)) == _lib.BL_UNEXPECTED
+    flac = open(os.path.join(HERE, "golden", "song.flac"), "rb").read()
+    cut = tmp_path / "cut.flac"
+    cut.write_bytes(flac[: len(flac) // 3])
+    rc = gpu_lib.bl_analyze(str(cut).encode(), C.byref(song))
+    assert rc in (_lib.BL_UNEXPECTED, _lib.BL_LOUD, _lib.BL_CALM, _lib.BL_UNKNOWN)  # never a crash
+    if rc != _lib.BL_UNEXPECTED:
+        gpu_lib.bl_free_song(C.byref(song))
+    txt = tmp_path / "notes.wav"
+    txt.write_text("not audio at all")
+    assert gpu_lib.bl_analyze(str(txt).encode(), C.byref(song)) == _lib.BL_UNEXPECTED
