@@ -906,16 +906,29 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_env_tail: one lane per song, 64 songs per wave                           */
+/* k_env_tail: one lane per song, two waves per 64 songs                      */
+/*
+ * Parts 2-3 of bl_envelope_sort are serial per song.  The 6th-order recurrence is a chain
+ * of 8 dependent f64 operations per step, everything after y_j (onset difference, weighted
+ * average, two box filters, peak test) another ~30; one wave issuing both in order needs
+ * ~340 cycles per step.  Here wave 0 of the workgroup runs the recurrence (bl_tail_iir) and
+ * hands y_j to wave 1 (bl_tail_post) through a double-buffered LDS block of 38 steps x 64
+ * songs; the two overlap and a step costs what the slower stage costs.
+ */
+#define BL_TAIL_TW 57 /* windows per staged input tile: 114 steps = three 38-step blocks */
 
-#define BL_TAIL_TW 57 /* windows per staged tile: 114 steps = 3 register-ring chunks of 38 */
-
-__global__ __launch_bounds__(64) void k_env_tail(const bl_dsong *__restrict__ songs,
-                                                 const double *__restrict__ lc, int n_songs,
-                                                 bl_amd_song_result *res, int what) {
-  __shared__ double tile[64 * (BL_TAIL_TW + 1)];
-  __shared__ double rings[48 * 64];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ songs,
+                                                  const double *__restrict__ lc, int n_songs,
+                                                  bl_amd_song_result *res, int what) {
+  __shared__ double tile[64 * (BL_TAIL_TW + 1)]; /* wave 0: compressed envelope, transposed */
+  __shared__ double yblk[2][38 * 64];            /* y_j of one block, [step][song] */
+  __shared__ double rings[48 * 64];              /* wave 1: box-filter rings */
+  __shared__ int flag_mem[2];
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  lds_vint *flags = (lds_vint *)flag_mem; /* [0]: blocks produced, [1]: blocks consumed */
+  /* a handful of latency-bound waves that run beside the wide kernels: let them issue first */
+  __builtin_amdgcn_s_setprio(3);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int song = blockIdx.x * 64 + lane;
   const bool valid = song < n_songs;
   bl_dsong sg;
@@ -928,52 +941,77 @@ __global__ __launch_bounds__(64) void k_env_tail(const bl_dsong *__restrict__ so
     maxN = max(maxN, __shfl_xor(maxN, off));
     minN = min(minN, __shfl_xor(minN, off));
   }
-  bl_tail t;
-  t.init(sg.nb_frames, rings + lane, 64);
-  const double *mine = tile + lane * (BL_TAIL_TW + 1);
+  if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+  __syncthreads();
+  const int n_blocks = (maxN + 37) / 38;
 
-  for (int j0 = 0; j0 < maxN; j0 += 2 * BL_TAIL_TW) {
-    /* stage BL_TAIL_TW windows x 64 songs of the compressed envelope, transposed;
-     * 16 independent loads in flight per lane */
-    const int wbase = j0 >> 1;
-    for (int sb = 0; sb < 64; sb += 16) {
-      double v[16];
+  if (wave == 0) {
+    /* ---- the recurrence: input pairs (x_j, 0) -> (y_j, y_j+1) ---- */
+    bl_tail_iir a;
+    a.init();
+    const double *mine = tile + lane * (BL_TAIL_TW + 1);
+    for (int kb = 0; kb < n_blocks; ++kb) {
+      const int sub = kb % 3;
+      if (sub == 0) {
+        /* stage BL_TAIL_TW windows x 64 songs of the compressed envelope, transposed;
+         * 16 independent loads in flight per lane */
+        const int wbase = 19 * kb;
+        bl_wave_sync();
+        for (int sb = 0; sb < 64; sb += 16) {
+          double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int nw = __shfl(sg.n_windows, sb + u);
-        const long long off = __shfl(sg.env_off, sb + u);
-        const int w = wbase + lane;
-        v[u] = (lane < BL_TAIL_TW && w < nw) ? lc[off + w] : 0.0;
+          for (int u = 0; u < 16; ++u) {
+            const int nw = __shfl(sg.n_windows, sb + u);
+            const long long off = __shfl(sg.env_off, sb + u);
+            const int w = wbase + lane;
+            v[u] = (lane < BL_TAIL_TW && w < nw) ? lc[off + w] : 0.0;
+          }
+          if (lane < BL_TAIL_TW) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tile[(sb + u) * (BL_TAIL_TW + 1) + lane] = v[u];
+          }
+        }
+        bl_wave_sync();
       }
-      if (lane < BL_TAIL_TW) {
+      double *yo = yblk[kb & 1] + lane;
+      double ye[38];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) tile[(sb + u) * (BL_TAIL_TW + 1) + lane] = v[u];
+      for (int q = 0; q < 19; ++q) a.pair(mine[19 * sub + q], ye[2 * q], ye[2 * q + 1]);
+      /* the buffer is free once the block before the previous one has been consumed */
+      while (__builtin_amdgcn_readfirstlane(flags[1]) < kb - 1) __builtin_amdgcn_s_sleep(1);
+      ev2_lds_acquire();
+#pragma unroll
+      for (int q = 0; q < 38; ++q) yo[q * 64] = ye[q];
+      ev2_lds_release();
+      bl_wave_sync();
+      if (lane == 0) flags[0] = kb + 1;
+    }
+    return;
+  }
+
+  /* ---- everything after y_j ---- */
+  bl_tail_post t;
+  t.init(sg.nb_frames, rings + lane, 64);
+  for (int kb = 0; kb < n_blocks; ++kb) {
+    while (__builtin_amdgcn_readfirstlane(flags[0]) < kb + 1) __builtin_amdgcn_s_sleep(1);
+    ev2_lds_acquire();
+    const double *yin = yblk[kb & 1] + lane;
+    const int j = 38 * kb;
+    /* wave-uniform: every song of the wave is in its steady state for the whole block */
+    if (bl_tail::chunk_ok(j, minN)) {
+      t.fast_chunk38(yin, 64);
+    } else {
+      for (int q = 0; q < 38; ++q) {
+        const int jj = j + q;
+        if (jj < N) {
+          t.step(jj, yin[q * 64]);
+          if (jj == N - 1) t.finish();
+        }
       }
     }
-    __syncthreads();
-    const int jend = min(2 * BL_TAIL_TW, maxN - j0);
-    int jj = 0;
-    while (jj < jend) {
-      const int j = j0 + jj;
-      /* wave-uniform: every song of the wave is in its steady state for the span */
-      if (jj + 38 <= jend && bl_tail::chunk_ok(j, minN)) {
-        t.fast_chunk38(mine + (jj >> 1), 1);
-        jj += 38;
-        continue;
-      }
-      if (jj + 1 < jend && bl_tail::fast_ok(j, minN)) {
-        t.fast_pair(mine[jj >> 1]);
-        jj += 2;
-        continue;
-      }
-      if (j < N) {
-        const double x = (jj & 1) ? 0.0 : mine[jj >> 1];
-        t.step(j, x);
-        if (j == N - 1) t.finish();
-      }
-      ++jj;
-    }
-    __syncthreads();
+    ev2_lds_release();
+    bl_wave_sync();
+    if (lane == 0) flags[1] = kb + 1;
   }
   if (!valid) return;
   bl_amd_song_result *r = res + sg.out_idx;
@@ -1438,7 +1476,7 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
     }
     {
       ProfScope ps(PK_TAIL, ts);
-      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(64), 0, ts, d_songs, d_lc, n_songs, d_results,
+      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(128), 0, ts, d_songs, d_lc, n_songs, d_results,
                          what);
     }
     if (tail_async) BL_HIP_CHECK(hipEventRecord(g.ev_tail, g.side));

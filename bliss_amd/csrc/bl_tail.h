@@ -363,6 +363,155 @@ struct bl_tail {
   BL_THD int beat() const { return st2.peaks.beat; }
 };
 
+/*
+ * The same stream cut in two at y_j, for two cooperating waves (k_env_tail): the recurrence
+ * is a chain of 8 dependent operations per step, everything downstream of y_j is ~30
+ * independent ones; one wave per 64 songs issues both in order (~340 cycles per step), two
+ * waves overlap them.  bl_tail_iir + bl_tail_post produce bit for bit what bl_tail does
+ * (tests/host/test_tail_host.cpp runs both against the oracle).
+ */
+struct bl_tail_iir {
+  double x2, x4, x6;             /* even inputs x[j-2], x[j-4], x[j-6]; odd ones are stuffed zeros */
+  double y1, y2, y3, y4, y5, y6; /* y[j-1..j-6] */
+  BL_THD void init() { x2 = x4 = x6 = 0; y1 = y2 = y3 = y4 = y5 = y6 = 0; }
+  BL_THD double feedback(double d) {
+    double c = 0; /* ref :214-215 */
+    c += BL_BUT_A1 * y1;
+    c += BL_BUT_A2 * y2;
+    c += BL_BUT_A3 * y3;
+    c += BL_BUT_A4 * y4;
+    c += BL_BUT_A5 * y5;
+    c += BL_BUT_A6 * y6;
+    const double y = (d - c) / BL_BUT_A0; /* ref :216 */
+    y6 = y5; y5 = y4; y4 = y3; y3 = y2; y2 = y1; y1 = y;
+    return y;
+  }
+  /* steps j (even, input x >= 0) and j + 1 (stuffed zero), any even j >= 0.  The feed-forward
+   * sums of ref :210-213 skip their `+= b[k] * 0.0` terms: every partial sum is a sum of
+   * products of positive taps with non-negative inputs, so adding +0.0 is the identity (and
+   * 0 + b0*x is b0*x) — the argument of bl_tail::fast_pair, which does not need j >= 40. */
+  BL_THD void pair(double x, double &y_even, double &y_odd) {
+    double d = BL_BUT_B0 * x;
+    d += BL_BUT_B2 * x2;
+    d += BL_BUT_B2 * x4;
+    d += BL_BUT_B0 * x6;
+    y_even = feedback(d);
+    double e = BL_BUT_B1 * x;
+    e += BL_BUT_B3 * x2;
+    e += BL_BUT_B1 * x4;
+    y_odd = feedback(e);
+    x6 = x4; x4 = x2; x2 = x;
+  }
+};
+
+struct bl_tail_post {
+  double yp; /* y[j-1] */
+  double atk;
+  bl_box19<true> box1;
+  bl_tail_stage2 st2;
+  double *ring1, *olds1;
+  int stride, N;
+
+  /* scratch: 19 + 10 + 19 doubles per song, element e at scratch[e * stride] */
+  BL_THD void init(int nb_frames, double *scratch, int stride_) {
+    yp = 0;
+    atk = 0;
+    N = 2 * nb_frames;
+    stride = stride_;
+    ring1 = scratch;
+    olds1 = scratch + 19 * stride_;
+    st2.ring = scratch + 29 * stride_;
+    st2.stride = stride_;
+    box1.init(N);
+    st2.box.init(N);
+    st2.peaks.init();
+  }
+
+  BL_THD double weighted(double y, double dj) {
+    const float lambda = 0.8f; /* ref :171 */
+    return (1 - lambda) * y + BL_DIV10(lambda * 172 * dj); /* ref :230-231 */
+  }
+
+  /* one step j = 0..N-1 from y_j (ref :221-263) */
+  BL_THD void step(int j, double y) {
+    double dj;
+    if (j == 0) dj = y;
+    else { dj = y - yp; dj = dj > 0 ? dj : 0; }
+    const double wa = weighted(y, dj);
+    yp = y;
+    double ss = 0;
+    if (j <= N - 2) { atk += wa; ss = wa; }
+    box1.push(ss, wa, ring1, olds1, stride, st2);
+  }
+
+  /* one steady step with both rings in registers (see bl_tail::reg_step) */
+  template <int P> BL_THD void reg_step(double y, double (&ra)[BL_BOX], double (&rb)[BL_BOX]) {
+    double dj = y - yp;
+    dj = dj > 0 ? dj : 0;
+    const double wa = weighted(y, dj);
+    yp = y;
+    atk += wa;
+    box1.run -= ra[P];
+    box1.run += wa;
+    ra[P] = wa;
+    const double o1 = BL_DIV19(box1.run);
+    st2.box.run -= rb[P];
+    st2.box.run += o1;
+    rb[P] = o1;
+    const double o2 = BL_DIV19(st2.box.run);
+    const float epsilon = 0.000001f;
+    const double dl = st2.peaks.p1 - st2.peaks.p2, dr = st2.peaks.p1 - o2;
+    st2.peaks.beat += (dl > epsilon && dr > epsilon) ? 1 : 0;
+    st2.peaks.p2 = st2.peaks.p1;
+    st2.peaks.p1 = o2;
+  }
+  template <int S> BL_THD void reg_steps(const double *yin, int ystride, double (&ra)[BL_BOX],
+                                         double (&rb)[BL_BOX]) {
+    if constexpr (S < 2 * BL_BOX) {
+      reg_step<S % BL_BOX>(yin[S * ystride], ra, rb);
+      reg_steps<S + 1>(yin, ystride, ra, rb);
+    }
+  }
+
+  /* 38 steady steps y_j .. y_(j+37) at yin[s * ystride]; requires bl_tail::chunk_ok(j, N) */
+  BL_THD void fast_chunk38(const double *yin, int ystride) {
+    double ra[BL_BOX], rb[BL_BOX];
+    {
+      int sa = box1.s19, sb = st2.box.s19;
+#pragma unroll
+      for (int k = 0; k < BL_BOX; ++k) {
+        ra[k] = ring1[sa * stride];
+        rb[k] = st2.ring[sb * stride];
+        sa = sa == BL_BOX - 1 ? 0 : sa + 1;
+        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
+      }
+    }
+    reg_steps<0>(yin, ystride, ra, rb);
+    {
+      int sa = box1.s19, sb = st2.box.s19;
+#pragma unroll
+      for (int k = 0; k < BL_BOX; ++k) {
+        ring1[sa * stride] = ra[k];
+        st2.ring[sb * stride] = rb[k];
+        sa = sa == BL_BOX - 1 ? 0 : sa + 1;
+        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
+      }
+    }
+    box1.t += 38;
+    st2.box.t += 38;
+    st2.peaks.i += 38;
+    /* see bl_tail::fast_chunk38 for the skipped olds1 stores */
+    box1.s10 = (box1.s10 + 8) % 10;
+    st2.box.s10 = (st2.box.s10 + 8) % 10;
+  }
+
+  BL_THD void finish() {
+    box1.finish(ring1, olds1, stride, st2);
+    st2.box.finish(st2.ring, (const double *)0, stride, st2.peaks);
+  }
+  BL_THD int beat() const { return st2.peaks.beat; }
+};
+
 /* ref src/tempo_atk_sort.c:186-188 with mu = 100.0f; log101 = log(1 + mu) */
 BL_THD double bl_tail_compress(double f, double log101) {
   const float mu = 100.0f;

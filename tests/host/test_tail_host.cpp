@@ -38,6 +38,25 @@ static int check(unsigned seed, unsigned rate, unsigned ch, unsigned secs, unsig
   t.finish();
   float tempo = bl_tail_tempo(t.beat(), secs), attack = bl_tail_attack(t.atk, (int)n);
   int ok = t.beat() == r.beat && t.atk == r.atk_sum && tempo == r.tempo && attack == r.attack;
+  // the two-stage form (recurrence | everything after y_j) used by k_env_tail: 38-step blocks
+  // from j = 0, register-ring chunks where the whole block is in the steady state
+  {
+    std::vector<double> scratch2(48), yv(N + 38, 0.0);
+    bl_tail_iir a;
+    bl_tail_post b;
+    a.init();
+    b.init(r.nb_frames, scratch2.data(), 1);
+    for (int j = 0; j < N; j += 2) a.pair(bl_tail_compress((double)en[j / 2], log101), yv[j], yv[j + 1]);
+    for (int j = 0; j < N; j += 38) {
+      if (use_fast && bl_tail::chunk_ok(j, N)) b.fast_chunk38(&yv[j], 1);
+      else
+        for (int q = j; q < j + 38 && q < N; ++q) b.step(q, yv[q]);
+    }
+    b.finish();
+    const int ok2 = b.beat() == r.beat && b.atk == r.atk_sum;
+    if (!ok2) printf("  two-stage: beat %d atk %.17g MISMATCH\n", b.beat(), b.atk);
+    ok &= ok2;
+  }
   printf("seed %u n %u: beat %d/%d atk %.17g/%.17g tempo %g attack %g %s\n", seed, n, t.beat(),
          r.beat, t.atk, r.atk_sum, tempo, attack, ok ? "ok" : "MISMATCH");
   return ok;
