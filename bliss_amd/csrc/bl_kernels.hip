@@ -998,7 +998,7 @@ __global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ s
     const double *yin = yblk[kb & 1] + lane;
     const int j = 38 * kb;
     /* wave-uniform: every song of the wave is in its steady state for the whole block */
-    if (bl_tail::chunk_ok(j, minN)) {
+    if (bl_tail_post::chunk_ok(j, minN)) {
       t.fast_chunk38(yin, 64);
     } else {
       for (int q = 0; q < 38; ++q) {

@@ -195,166 +195,6 @@ struct bl_tail {
     box1.push(ss, wa, ring1, olds1, stride, st2);
   }
 
-  /* ---- steady-state fast path -------------------------------------------------
-   * For 40 <= j <= N - 12 every conditional of step() is decided (both box filters
-   * and the peak detector emit exactly one value per step), so two steps (even j with
-   * input x, odd j+1 with the stuffed zero) can run as straight-line code.  The
-   * feed-forward sum skips its `+= b[k] * 0.0` terms: every partial sum is a sum of
-   * products of positive taps with non-negative inputs, so adding +0.0 is the identity.
-   * Same values, same order, bit-identical to step() (tests/host/test_tail_host.cpp). */
-  BL_THD static bool fast_ok(int j, int n) { return (j & 1) == 0 && j >= 40 && j + 1 <= n - 12; }
-
-  BL_THD void fast_tail(double y, double wa) {
-    atk += wa;
-    double *r1 = ring1 + box1.s19 * stride;
-    box1.run -= *r1;
-    box1.run += wa;
-    *r1 = wa;
-    olds1[box1.s10 * stride] = wa;
-    const double o1 = BL_DIV19(box1.run);
-    ++box1.t;
-    box1.s19 = box1.s19 == BL_BOX - 1 ? 0 : box1.s19 + 1;
-    box1.s10 = box1.s10 == 9 ? 0 : box1.s10 + 1;
-    double *r2 = st2.ring + st2.box.s19 * stride;
-    st2.box.run -= *r2;
-    st2.box.run += o1;
-    *r2 = o1;
-    const double o2 = BL_DIV19(st2.box.run);
-    ++st2.box.t;
-    st2.box.s19 = st2.box.s19 == BL_BOX - 1 ? 0 : st2.box.s19 + 1;
-    st2.box.s10 = st2.box.s10 == 9 ? 0 : st2.box.s10 + 1;
-    const float epsilon = 0.000001f;
-    const double dl = st2.peaks.p1 - st2.peaks.p2, dr = st2.peaks.p1 - o2;
-    st2.peaks.beat += (dl > epsilon && dr > epsilon) ? 1 : 0;
-    st2.peaks.p2 = st2.peaks.p1;
-    st2.peaks.p1 = o2;
-    ++st2.peaks.i;
-    (void)y;
-  }
-
-  BL_THD double fast_feedback(double d) {
-    double c = 0;
-    c += BL_BUT_A1 * y1;
-    c += BL_BUT_A2 * y2;
-    c += BL_BUT_A3 * y3;
-    c += BL_BUT_A4 * y4;
-    c += BL_BUT_A5 * y5;
-    c += BL_BUT_A6 * y6;
-    const double y = (d - c) / BL_BUT_A0;
-    double dj = y - y1;
-    dj = dj > 0 ? dj : 0;
-    const float lambda = 0.8f;
-    const double wa = (1 - lambda) * y + BL_DIV10(lambda * 172 * dj);
-    y6 = y5; y5 = y4; y4 = y3; y3 = y2; y2 = y1; y1 = y;
-    fast_tail(y, wa);
-    return y;
-  }
-
-  /* one steady step with the two box-filter rings held in registers: ra / rb are the
-   * 19 most recent inputs of box 1 / box 2 in ring order, P the (static) ring slot */
-  template <int P> BL_THD void reg_step(double d, double (&ra)[BL_BOX], double (&rb)[BL_BOX]) {
-    double c = 0;
-    c += BL_BUT_A1 * y1;
-    c += BL_BUT_A2 * y2;
-    c += BL_BUT_A3 * y3;
-    c += BL_BUT_A4 * y4;
-    c += BL_BUT_A5 * y5;
-    c += BL_BUT_A6 * y6;
-    const double y = (d - c) / BL_BUT_A0;
-    double dj = y - y1;
-    dj = dj > 0 ? dj : 0;
-    const float lambda = 0.8f;
-    const double wa = (1 - lambda) * y + BL_DIV10(lambda * 172 * dj);
-    y6 = y5; y5 = y4; y4 = y3; y3 = y2; y2 = y1; y1 = y;
-    atk += wa;
-    box1.run -= ra[P];
-    box1.run += wa;
-    ra[P] = wa;
-    const double o1 = BL_DIV19(box1.run);
-    st2.box.run -= rb[P];
-    st2.box.run += o1;
-    rb[P] = o1;
-    const double o2 = BL_DIV19(st2.box.run);
-    const float epsilon = 0.000001f;
-    const double dl = st2.peaks.p1 - st2.peaks.p2, dr = st2.peaks.p1 - o2;
-    st2.peaks.beat += (dl > epsilon && dr > epsilon) ? 1 : 0;
-    st2.peaks.p2 = st2.peaks.p1;
-    st2.peaks.p1 = o2;
-  }
-
-  template <int Q> BL_THD void reg_pairs(const double *xin, int xstride, double (&ra)[BL_BOX],
-                                         double (&rb)[BL_BOX]) {
-    if constexpr (Q < BL_BOX) {
-      const double x = xin[Q * xstride];
-      double d = BL_BUT_B0 * x;
-      d += BL_BUT_B2 * x2;
-      d += BL_BUT_B2 * x4;
-      d += BL_BUT_B0 * x6;
-      reg_step<(2 * Q) % BL_BOX>(d, ra, rb);
-      double e = BL_BUT_B1 * x;
-      e += BL_BUT_B3 * x2;
-      e += BL_BUT_B1 * x4;
-      reg_step<(2 * Q + 1) % BL_BOX>(e, ra, rb);
-      x6 = x4; x4 = x2; x2 = x;
-      reg_pairs<Q + 1>(xin, xstride, ra, rb);
-    }
-  }
-
-  /* 38 steady steps (19 even inputs xin[q * xstride]) starting at even j; requires
-   * fast_ok(j, N) and fast_ok(j + 36, N).  38 = 2 * 19 steps are two full turns of both
-   * rings, so the rings come back to LDS in the slots they left and no counter other
-   * than t / s10 moves.  Box 2 lags box 1 by 9 inputs and the peak detector by 18, but
-   * all three see exactly one value per step. */
-  BL_THD static bool chunk_ok(int j, int n) { return fast_ok(j, n) && fast_ok(j + 36, n); }
-
-  BL_THD void fast_chunk38(const double *xin, int xstride) {
-    double ra[BL_BOX], rb[BL_BOX];
-    {
-      int sa = box1.s19, sb = st2.box.s19;
-#pragma unroll
-      for (int k = 0; k < BL_BOX; ++k) {
-        ra[k] = ring1[sa * stride];
-        rb[k] = st2.ring[sb * stride];
-        sa = sa == BL_BOX - 1 ? 0 : sa + 1;
-        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
-      }
-    }
-    reg_pairs<0>(xin, xstride, ra, rb);
-    {
-      int sa = box1.s19, sb = st2.box.s19;
-#pragma unroll
-      for (int k = 0; k < BL_BOX; ++k) {
-        ring1[sa * stride] = ra[k];
-        st2.ring[sb * stride] = rb[k];
-        sa = sa == BL_BOX - 1 ? 0 : sa + 1;
-        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
-      }
-    }
-    box1.t += 38;
-    st2.box.t += 38;
-    st2.peaks.i += 38;
-    /* the skipped olds1 stores are all overwritten before finish() reads them: at least
-     * 11 generic steps follow any chunk (fast_ok), olds1 holds 10 */
-    box1.s10 = (box1.s10 + 8) % 10;
-    st2.box.s10 = (st2.box.s10 + 8) % 10;
-  }
-
-  /* steps j (even, input x) and j+1 (odd, zero); requires fast_ok(j, N) */
-  BL_THD void fast_pair(double x) {
-    /* even: x2, x4, x6 are the previous even inputs; x1, x3, x5 are stuffed zeros */
-    double d = BL_BUT_B0 * x;
-    d += BL_BUT_B2 * x2;
-    d += BL_BUT_B2 * x4;
-    d += BL_BUT_B0 * x6;
-    fast_feedback(d);
-    /* odd: the inputs one, three and five steps back are x, x2, x4 */
-    double e = BL_BUT_B1 * x;
-    e += BL_BUT_B3 * x2;
-    e += BL_BUT_B1 * x4;
-    fast_feedback(e);
-    x6 = x4; x4 = x2; x2 = x; /* x1, x3, x5 stay 0 */
-  }
-
   BL_THD void finish() {
     box1.finish(ring1, olds1, stride, st2);
     st2.box.finish(st2.ring, (const double *)0, stride, st2.peaks);
@@ -365,10 +205,10 @@ struct bl_tail {
 
 /*
  * The same stream cut in two at y_j, for two cooperating waves (k_env_tail): the recurrence
- * is a chain of 8 dependent operations per step, everything downstream of y_j is ~30
- * independent ones; one wave per 64 songs issues both in order (~340 cycles per step), two
- * waves overlap them.  bl_tail_iir + bl_tail_post produce bit for bit what bl_tail does
- * (tests/host/test_tail_host.cpp runs both against the oracle).
+ * is a chain of 8 dependent operations per step, everything downstream of y_j is ~30 more;
+ * one wave per 64 songs issues both in order (~340 cycles per step), two waves overlap
+ * them.  bl_tail above is the plain one-step-at-a-time form; bl_tail_iir + bl_tail_post
+ * produce bit for bit the same (tests/host/test_tail_host.cpp runs both against the oracle).
  */
 struct bl_tail_iir {
   double x2, x4, x6;             /* even inputs x[j-2], x[j-4], x[j-6]; odd ones are stuffed zeros */
@@ -389,7 +229,7 @@ struct bl_tail_iir {
   /* steps j (even, input x >= 0) and j + 1 (stuffed zero), any even j >= 0.  The feed-forward
    * sums of ref :210-213 skip their `+= b[k] * 0.0` terms: every partial sum is a sum of
    * products of positive taps with non-negative inputs, so adding +0.0 is the identity (and
-   * 0 + b0*x is b0*x) — the argument of bl_tail::fast_pair, which does not need j >= 40. */
+   * 0 + b0*x is b0*x). */
   BL_THD void pair(double x, double &y_even, double &y_odd) {
     double d = BL_BUT_B0 * x;
     d += BL_BUT_B2 * x2;
@@ -427,6 +267,13 @@ struct bl_tail_post {
     st2.peaks.init();
   }
 
+  /* Steady state: for 40 <= j <= N - 12 every conditional of step() is decided (both box
+   * filters and the peak detector emit exactly one value per step; box 2 lags box 1 by 9
+   * inputs and the peak detector by 18).  A block of 38 = 2 * 19 steps is two full turns of
+   * both rings, so they can live in registers and come back to the slots they left. */
+  BL_THD static bool steady(int j, int n) { return (j & 1) == 0 && j >= 40 && j + 1 <= n - 12; }
+  BL_THD static bool chunk_ok(int j, int n) { return steady(j, n) && steady(j + 36, n); }
+
   BL_THD double weighted(double y, double dj) {
     const float lambda = 0.8f; /* ref :171 */
     return (1 - lambda) * y + BL_DIV10(lambda * 172 * dj); /* ref :230-231 */
@@ -444,7 +291,8 @@ struct bl_tail_post {
     box1.push(ss, wa, ring1, olds1, stride, st2);
   }
 
-  /* one steady step with both rings in registers (see bl_tail::reg_step) */
+  /* one steady step with the two box-filter rings held in registers: ra / rb are the 19 most
+   * recent inputs of box 1 / box 2 in ring order, P the (static) ring slot */
   template <int P> BL_THD void reg_step(double y, double (&ra)[BL_BOX], double (&rb)[BL_BOX]) {
     double dj = y - yp;
     dj = dj > 0 ? dj : 0;
@@ -473,7 +321,7 @@ struct bl_tail_post {
     }
   }
 
-  /* 38 steady steps y_j .. y_(j+37) at yin[s * ystride]; requires bl_tail::chunk_ok(j, N) */
+  /* 38 steady steps y_j .. y_(j+37) at yin[s * ystride]; requires chunk_ok(j, N) */
   BL_THD void fast_chunk38(const double *yin, int ystride) {
     double ra[BL_BOX], rb[BL_BOX];
     {
@@ -500,7 +348,8 @@ struct bl_tail_post {
     box1.t += 38;
     st2.box.t += 38;
     st2.peaks.i += 38;
-    /* see bl_tail::fast_chunk38 for the skipped olds1 stores */
+    /* the skipped olds1 stores are all overwritten before finish() reads them: at least
+     * 11 generic steps follow any chunk (steady), olds1 holds 10 */
     box1.s10 = (box1.s10 + 8) % 10;
     st2.box.s10 = (st2.box.s10 + 8) % 10;
   }
