@@ -78,7 +78,23 @@ def cpu_baseline(seconds_budget=25.0):
                 break
     except OSError:
         pass
+    # second half of the metric: the 10 000 x 10 000 bl_distance matrix as the nested loop of
+    # the reference's per-pair function, one core
+    dm_cpu = None
+    try:
+        import numpy as np
+        from tests.oracle_py import Oracle
+        orc = Oracle()
+        v = (np.random.default_rng(4).standard_normal((10000, 4)) * 8).astype(np.float32)
+        out = np.empty((10000, 10000), dtype=np.float32)
+        t1 = time.time()
+        orc.lib.orc_distance_matrix(v.ctypes.data_as(C.POINTER(C.c_float)), 10000,
+                                    out.ctypes.data_as(C.POINTER(C.c_float)))
+        dm_cpu = time.time() - t1
+    except Exception:
+        pass
     return {"value": rate, "unit": "songs/s", "cores": cores, "kind": "port",
+            "distance_matrix_10k_s_one_core": dm_cpu,
             "sample": f"{done} synthetic 3-min 44.1 kHz s16 stereo songs, {per_proc} per process, "
                       f"{cores} concurrent processes (one per hardware thread), analysis time only; "
                       f"wall {wall:.1f} s incl. synthesis; 1 core alone: {one['songs_per_s']:.3f} songs/s",
