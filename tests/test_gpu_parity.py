@@ -358,3 +358,17 @@ def test_invalid_inputs_are_rejected(gpu_lib, tmp_path):
     txt = tmp_path / "notes.wav"
     txt.write_text("not audio at all")
     assert gpu_lib.bl_analyze(str(txt).encode(), C.byref(song)) == _lib.BL_UNEXPECTED
+
+
+def test_c_caller_links_and_passes(gpu_lib, tmp_path):
+    """tests/c/dropin_check.c: a C99 caller compiled against include/bliss.h only and linked against
+    libbliss_amd.so, checking the reference's goldens for song.flac and the by-value struct ABI."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "dropin_check")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                    os.path.join(HERE, "c", "dropin_check.c"), "-o", exe,
+                    "-L", os.path.join(root, "bliss_amd"), "-lbliss_amd", "-lm",
+                    "-Wl,-rpath," + os.path.join(root, "bliss_amd")], check=True)
+    r = subprocess.run([exe, os.path.join(HERE, "golden", "song.flac")], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout
