@@ -1697,6 +1697,9 @@ int bl_amd_cosine_matrix_host(const struct force_vector_s *h_vecs, int n, float 
 }
 
 /* ---- host-memory batch: pinned staging, copy/compute overlap on 2 streams ---- */
+#ifndef BL_STAGE_THREADS
+#define BL_STAGE_THREADS 8 /* host threads of the staging copy */
+#endif
 int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samples,
                               const int32_t *channels, const uint64_t *duration, int n_songs,
                               bl_amd_song_result *h_results) {
@@ -1749,7 +1752,7 @@ int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samp
     int16_t *stage = static_cast<int16_t *>(g.pinned[k]);
     {
       /* staging copy on several host threads: one thread moves ~10 GB/s, the link takes 50+ */
-      const int n_thr = (int)std::min<size_t>(8, std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
+      const int n_thr = (int)std::min<size_t>(BL_STAGE_THREADS, std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
       auto copy_range = [&](int t) {
         for (size_t i = (size_t)t; i < desc.size(); i += (size_t)n_thr) {
           memcpy(stage + desc[i].pcm_offset, h_pcm[begin + i], (size_t)desc[i].n_samples * 2);
