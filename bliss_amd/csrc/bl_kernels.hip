@@ -60,7 +60,7 @@ struct bl_dsong {
   int n_frames;  /* (n / channels) / 512              ref frequency_sort.c:50 */
   int nb_frames; /* 2 * floor(n / 512)                ref tempo_atk_sort.c:63-64 */
   int n_windows; /* nb_frames - 2 windows of hop 256  ref tempo_atk_sort.c:66-67,120 */
-  int part_off;  /* first partial-spectrum slot of this song (256 frames per slot) */
+  int part_off;  /* unused (was: first partial-spectrum slot) */
   int out_idx;   /* result slot = position in the caller's order (records are length-sorted) */
   int pad;
 };
@@ -383,48 +383,48 @@ struct bl_tables {
   double log101;
 };
 
-#define BL_FREQ_CHUNK 256 /* frames per partial spectrum */
-/* exchange buffers (the partner half rows reuse them), twiddles, Hann; + histogram when
- * the scan is fused.  40.8 KB -> three workgroups per CU (the kernel needs 158 VGPRs) */
-#define BL_FREQ_LDS_BYTES(scan)                                                        \
-  (16 * BL_FFT_XCH_ELEMS * 8 + 2 * 256 * 8 + 512 * 4 + ((scan) ? BL_HIST_BINS * 4 : 0))
+/* exchange buffers (the partner half rows and the per-wave power staging reuse them),
+ * twiddles, Hann, the running spectrum and the relay word: 41.9 KB -> three workgroups per CU
+ * (the kernel needs ~160 VGPRs) */
+#define BL_FREQ_ACC_OFF (16 * BL_FFT_XCH_ELEMS * 8 + 2 * 256 * 8 + 512 * 4)
+#define BL_FREQ_LDS_BYTES (BL_FREQ_ACC_OFF + 256 * 4 + 64)
 
-/* SCAN = true fuses k_pcm_scan's statistics into the same pass over the PCM (the frames
- * cover every sample except a tail shorter than one frame, which the block that owns the
- * last chunk scans separately), so the analysis reads the PCM twice instead of three times. */
-template <bool SCAN>
+/*
+ * One workgroup per song, its frames in order.  ref src/frequency_sort.c:88-93 adds every
+ * frame's power spectrum into one f32 accumulator per bin, frame after frame; f32 addition
+ * does not associate, so the order is part of the result (15 000 frames leave ~1e-5 of room
+ * in `frequency`).  Each 16-lane group transforms one frame, a wave four consecutive frames
+ * per iteration, the four waves 16; the running spectrum then goes round the waves like a
+ * baton: wave w waits for the relay word to reach 4 * it + w, adds its four frames bin by bin
+ * in frame order (its own power values re-laid out through its private exchange space: lane
+ * j owns bins j, j + 64, j + 128, j + 192) and passes it on.  No workgroup barrier in the
+ * loop; the waves stagger themselves by a quarter iteration.
+ */
 __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__ pcm,
                                                      const bl_dsong *__restrict__ songs,
-                                                     bl_tables tb, float *partial, bl_dstats *stats,
-                                                     unsigned *hist) {
+                                                     bl_tables tb, float *spectrum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c2f *xch = reinterpret_cast<c2f *>(smem);                       /* 16 x 272 */
   c2f *tw256 = xch + 16 * BL_FFT_XCH_ELEMS;
   c2f *tw512 = tw256 + 256;
   float *hann = reinterpret_cast<float *>(tw512 + 256);
-  unsigned *lh = reinterpret_cast<unsigned *>(hann + 512);        /* SCAN: 4096-bin histogram */
+  float *accv = reinterpret_cast<float *>(smem + BL_FREQ_ACC_OFF); /* ps[0..255] so far */
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF + 256 * 4);
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-  const bl_dsong sg = songs[blockIdx.y];
+  const int wave = tid >> 6, lane = tid & 63, gl = g & 3;
+  const bl_dsong sg = songs[blockIdx.x];
   const int16_t *p = pcm + sg.pcm_off;
   tw256[tid] = tb.tw256_f[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
   tw512[tid] = tb.tw512_f[tid];
   hann[tid] = tb.hann[tid];
   hann[tid + 256] = tb.hann[tid + 256];
-  if (SCAN)
-    for (int i = tid; i < BL_HIST_BINS; i += 256) lh[i] = 0;
+  accv[tid] = 0.f;
+  if (tid == 0) relay[0] = 0;
   __syncthreads();
-  long long ssum = 0;
-  unsigned long long ssq = 0;
-  unsigned sfirst = 0xFFFFFFFFu;
-  int slast = -1;
 
   c2f *gx = xch + g * BL_FFT_XCH_ELEMS, *gp = gx; /* partner rows alias the transpose */
-  float *red = reinterpret_cast<float *>(smem); /* [16][256], aliases xch */
-  /* The frames of a song are cut into fixed chunks of BL_FREQ_CHUNK (independent of
-   * the launch geometry), so a song's result never depends on what else is in the
-   * batch: within a chunk each 16-lane group adds its frames in frame order, the 16
-   * groups are folded in group order, k_freq_finish adds the chunks in chunk order. */
-  const int parts = (sg.n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
+  float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [4][257] */
   /* one frame ahead: 16 unconditional loads per lane (frame index clamped into the song,
    * an inactive frame is zeroed when it is consumed), so the HBM latency of frame f+1
    * hides behind the transform of frame f */
@@ -442,102 +442,63 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
       for (int m1 = 0; m1 < 16; ++m1) pre[m1] = make_uint2(q[16 * m1 + l], 0u);
     }
   };
-  fetch(blockIdx.x * BL_FREQ_CHUNK + g);
-  for (int chunk = blockIdx.x; chunk < parts; chunk += gridDim.x) {
-    float a_own[8], a_mir[8], a_mid = 0.f;
+  const int n_iter = (sg.n_frames + 15) / 16;
+  fetch(g);
+  for (int it = 0; it < n_iter; ++it) {
+    const int f = it * 16 + g;
+    const bool active = f < sg.n_frames;
+    float re[16], im[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { a_own[k] = 0.f; a_mir[k] = 0.f; }
-    for (int it = 0; it < BL_FREQ_CHUNK / 16; ++it) {
-      const int f = chunk * BL_FREQ_CHUNK + it * 16 + g;
-      const bool active = f < sg.n_frames;
-      float re[16], im[16];
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) {
-        const uint2 w = pre[m1];
-        const int d = 32 * m1 + 2 * l;
-        const int a0 = (int)(short)(w.x & 0xFFFFu), a1 = (int)(short)(w.x >> 16);
-        const int a2 = (int)(short)(w.y & 0xFFFFu), a3 = (int)(short)(w.y >> 16);
-        if (SCAN && active) {
-          if (stereo) {
-            const unsigned i0 = (unsigned)f * 1024u + 2u * (unsigned)d;
-            scan_sample(a0, i0, ssum, ssq, sfirst, slast, lh);
-            scan_sample(a1, i0 + 1u, ssum, ssq, sfirst, slast, lh);
-            scan_sample(a2, i0 + 2u, ssum, ssq, sfirst, slast, lh);
-            scan_sample(a3, i0 + 3u, ssum, ssq, sfirst, slast, lh);
-          } else {
-            const unsigned i0 = (unsigned)f * 512u + (unsigned)d;
-            scan_sample(a0, i0, ssum, ssq, sfirst, slast, lh);
-            scan_sample(a1, i0 + 1u, ssum, ssq, sfirst, slast, lh);
-          }
-        }
-        /* stereo, ref :69-75: (float)((L + R) / 2) * hann[d], the integer average truncates;
-         * mono, ref :76-80: (float)s * hann[d] */
-        const int s0 = stereo ? (a0 + a1) / 2 : a0;
-        const int s1 = stereo ? (a2 + a3) / 2 : a1;
-        re[m1] = active ? (float)s0 * hann[d] : 0.f;
-        im[m1] = active ? (float)s1 * hann[d + 1] : 0.f;
-      }
-      fetch(it + 1 < BL_FREQ_CHUNK / 16 ? f + 16 : (chunk + (int)gridDim.x) * BL_FREQ_CHUNK + g);
-      /* the exchange buffers of a 16-lane group are private to it, hence to its wave: no
-       * workgroup barrier inside the frame loop, the four waves drift apart freely */
-      bl_fft512_phaseA<float>(l, re, im, tw256, gx);
-      bl_wave_sync();
-      bl_fft512_phaseB_load<float>(l, re, im, gx);
-      bl_wave_sync();
-      bl_fft512_phaseB_publish<float>(l, re, im, gp);
-      bl_wave_sync();
-      float own[8], mir[8], mid;
-      bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
-      if (active) { /* ref :88-93: power_spectrum[d] += re*re + im*im */
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { a_own[k] += own[k]; a_mir[k] += mir[k]; }
-        a_mid += mid;
-      }
-      bl_wave_sync();
+    for (int m1 = 0; m1 < 16; ++m1) {
+      const uint2 w = pre[m1];
+      const int d = 32 * m1 + 2 * l;
+      const int a0 = (int)(short)(w.x & 0xFFFFu), a1 = (int)(short)(w.x >> 16);
+      const int a2 = (int)(short)(w.y & 0xFFFFu), a3 = (int)(short)(w.y >> 16);
+      /* stereo, ref :69-75: (float)((L + R) / 2) * hann[d], the integer average truncates;
+       * mono, ref :76-80: (float)s * hann[d] */
+      const int s0 = stereo ? (a0 + a1) / 2 : a0;
+      const int s1 = stereo ? (a2 + a3) / 2 : a1;
+      re[m1] = active ? (float)s0 * hann[d] : 0.f;
+      im[m1] = active ? (float)s1 * hann[d + 1] : 0.f;
     }
-    __syncthreads(); /* every wave is out of its exchanges: the region becomes `red` */
-    /* fold the 16 groups of the block in a fixed order */
+    fetch(f + 16);
+    /* the exchange buffers of a 16-lane group are private to it, hence to its wave */
+    bl_fft512_phaseA<float>(l, re, im, tw256, gx);
+    bl_wave_sync();
+    bl_fft512_phaseB_load<float>(l, re, im, gx);
+    bl_wave_sync();
+    bl_fft512_phaseB_publish<float>(l, re, im, gp);
+    bl_wave_sync();
+    float own[8], mir[8], mid;
+    bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
+    bl_wave_sync(); /* partner rows are consumed: the wave's exchange space becomes `stage` */
+    /* ref :88-93: re*re + im*im of bin d, for d = 1..255 (an inactive frame contributes +0) */
+    float *sg_ = stage + gl * 257;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      red[g * 256 + l + 16 * k] = a_own[k];
-      if (l + 16 * k != 0) red[g * 256 + 256 - l - 16 * k] = a_mir[k];
+      sg_[l + 16 * k] = own[k];
+      sg_[256 - l - 16 * k] = mir[k];
     }
-    if (l == 0) red[g * 256 + 128] = a_mid;
-    __syncthreads();
-    float acc = 0.f;
+    if (l == 0) sg_[128] = mid;
+    bl_wave_sync();
+    /* the baton: frames 16 it + 4 w .. + 3 join the running spectrum after those of wave w - 1 */
+    const int turn = 4 * it + wave;
+    while (__builtin_amdgcn_readfirstlane(relay[0]) < turn) __builtin_amdgcn_s_sleep(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int gg = 0; gg < 16; ++gg) acc += red[gg * 256 + tid];
-    partial[((size_t)sg.part_off + chunk) * 256 + tid] = acc;
-    __syncthreads();
-  }
-  if (SCAN) {
-    /* samples past the last whole frame (fewer than 512 * channels) */
-    if (blockIdx.x == 0) {
-      const unsigned covered = (unsigned)sg.n_frames * 512u * (unsigned)sg.channels;
-      for (unsigned i = covered + tid; i < (unsigned)sg.n; i += 256u)
-        scan_sample((int)p[i], i, ssum, ssq, sfirst, slast, lh);
-    }
+    for (int q = 0; q < 4; ++q) {
+      const int bin = lane + 64 * q;
+      float acc = accv[bin];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      ssum += __shfl_down(ssum, off);
-      ssq += __shfl_down(ssq, off);
-      sfirst = min(sfirst, (unsigned)__shfl_down((int)sfirst, off));
-      slast = max(slast, __shfl_down(slast, off));
+      for (int fr = 0; fr < 4; ++fr) acc += stage[fr * 257 + bin];
+      accv[bin] = acc;
     }
-    bl_dstats *st = stats + blockIdx.y;
-    if ((tid & 63) == 0) {
-      atomicAdd(&st->sum, (unsigned long long)ssum);
-      atomicAdd(&st->sumsq, ssq);
-      atomicMin(&st->first, sfirst);
-      atomicMax(&st->last, slast);
-    }
-    __syncthreads();
-    unsigned *gh = hist + (size_t)blockIdx.y * BL_HIST_BINS;
-    for (int i = tid; i < BL_HIST_BINS; i += 256) {
-      const unsigned c = lh[i];
-      if (c) atomicAdd(&gh[i], c);
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bl_wave_sync();
+    if (lane == 0) relay[0] = turn + 1;
   }
+  __syncthreads();
+  spectrum[(size_t)blockIdx.x * 256 + tid] = accv[tid];
 }
 
 __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ partial,
@@ -547,9 +508,7 @@ __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ p
   __shared__ float wmax[4];
   const int d = threadIdx.x, song = blockIdx.x;
   float acc = 0.f;
-  const int parts = (songs[song].n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
-  const float *pp = partial + (size_t)songs[song].part_off * 256 + d;
-  for (int k = 0; k < parts; ++k) acc += pp[(size_t)k * 256];
+  acc = partial[(size_t)song * 256 + d];
   /* ref :97-102: sqrt(ps / 512), peak over d = 1..256 (ps[256] is 0) */
   float v = d == 0 ? 0.f : (float)sqrt((double)(acc / 512));
   float m = v;
@@ -1194,7 +1153,6 @@ struct Ctx {
   std::mutex mu;
   bool ready = false;
   int env_dbg = 0;
-  bool fuse_scan = false;
   hipStream_t side = nullptr; /* envelope tail runs here, beside the frequency pass */
   hipEvent_t ev_env = nullptr, ev_tail = nullptr;
   bool side_ok = false;
@@ -1282,15 +1240,9 @@ int init_locked(int device) {
   {
     const char *d = getenv("BL_AMD_ENV_DBG"); /* bit 0: skip the ordered sums, bit 1: skip compute */
     g.env_dbg = d ? atoi(d) : 0;
-    const char *f = getenv("BL_AMD_FUSE_SCAN");
-    g.fuse_scan = f && f[0] == '1';
   }
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   BL_FREQ_LDS_BYTES(false)));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   BL_FREQ_LDS_BYTES(true)));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   if (!g.side_ok) {
     BL_HIP_CHECK(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
     BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_env, hipEventDisableTiming));
@@ -1334,11 +1286,10 @@ void prof_collect() {
 /* host mirror of the per-song geometry (integer work of ref tempo_atk_sort.c:63-67,
  * frequency_sort.c:50) */
 int fill_songs(const bl_amd_song_desc *desc, int n_songs, std::vector<bl_dsong> &out,
-               long long &env_total, int &max_n, long long *parts_total = nullptr) {
+               long long &env_total, int &max_n) {
   out.resize(n_songs);
   env_total = 0;
   max_n = 0;
-  long long parts = 0;
   for (int i = 0; i < n_songs; ++i) {
     const bl_amd_song_desc &d = desc[i];
     if (d.n_samples < 5120 || (d.channels != 1 && d.channels != 2) || d.duration == 0 ||
@@ -1359,14 +1310,12 @@ int fill_songs(const bl_amd_song_desc *desc, int n_songs, std::vector<bl_dsong> 
     s.nb_frames = (d.n_samples - (d.n_samples % 512)) * 2 / 512;
     s.n_windows = s.nb_frames - 2;
     s.env_off = env_total;
-    s.part_off = (int)parts;
+    s.part_off = 0;
     s.out_idx = i;
     s.pad = 0;
-    parts += (s.n_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK;
     env_total += s.nb_frames;
     if (d.n_samples > max_n) max_n = d.n_samples;
   }
-  if (parts_total) *parts_total = parts;
   /* Mixed-length corpora: process the records longest first.  The 64 songs that share a
    * wave of k_env_tail then have similar lengths (its straight-line steady-state path is
    * wave-uniform), and the long songs do not straggle at the end of the per-song grids.
@@ -1397,17 +1346,15 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   std::vector<bl_dsong> hs;
   long long env_total = 0;
   int max_n = 0;
-  long long parts_total = 0;
-  if (fill_songs(h_desc, n_songs, hs, env_total, max_n, &parts_total) != BL_OK) return BL_UNEXPECTED;
+  if (fill_songs(h_desc, n_songs, hs, env_total, max_n) != BL_OK) return BL_UNEXPECTED;
 
   const int max_frames = (max_n / 512);
   const int gx_scan = grid_x_for(((long long)max_n / 8 + 255) / 256, n_songs, 8);
-  const int gx_freq = grid_x_for((max_frames + BL_FREQ_CHUNK - 1) / BL_FREQ_CHUNK, n_songs, 6);
 
   if (ensure(g.songs, sizeof(bl_dsong) * n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.stats, sizeof(bl_dstats) * n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.hist, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.partial, sizeof(float) * 256 * (size_t)(parts_total + 1)) != BL_OK) return BL_UNEXPECTED;
+  if (ensure(g.partial, sizeof(float) * 256 * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.energies, sizeof(float) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.lc, sizeof(double) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
 
@@ -1426,16 +1373,7 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   BL_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
   const int tb64 = (n_songs + 63) / 64;
   hipLaunchKernelGGL(k_stats_init, dim3(tb64), dim3(64), 0, stream, d_stats, n_songs);
-  /* k_freq_frames<true> can gather the statistics in the same pass (2 PCM reads instead of
-   * 3), but measured 49 ms against 9.6 + 9.9 ms for the two separate passes (1 024 S180
-   * songs): the histogram's LDS atomics queue in front of every barrier of the DFT
-   * exchanges.  Kept selectable (BL_AMD_FUSE_SCAN=1) until the histogram is cheaper. */
-  const bool fused = (what & 2) != 0 && g.fuse_scan;
-  if (fused) {
-    ProfScope ps(PK_FREQ, stream);
-    hipLaunchKernelGGL(k_freq_frames<true>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES(true),
-                       stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
-  } else {
+  {
     ProfScope ps(PK_SCAN, stream);
     if (getenv("BL_AMD_SCAN_NOHIST")) /* measurement aid: cost of the LDS histogram */
       hipLaunchKernelGGL(k_pcm_scan<false>, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm,
@@ -1491,10 +1429,10 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
                        d_results);
   }
   if (what & 2) {
-    if (!fused) {
+    {
       ProfScope ps(PK_FREQ, stream);
-      hipLaunchKernelGGL(k_freq_frames<false>, dim3(gx_freq, n_songs), dim3(256), BL_FREQ_LDS_BYTES(false),
-                         stream, d_pcm, d_songs, g.tb, d_partial, d_stats, d_hist);
+      hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream, d_pcm,
+                         d_songs, g.tb, d_partial);
     }
     ProfScope ps(PK_FREQ_FIN, stream);
     hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, d_songs,

@@ -92,6 +92,8 @@ def main():
         refs = dict(pool.imap_unordered(_oracle_one, [(s, a.max_seconds) for s in seeds], chunksize=1))
     t2 = time.time()
     bad_int, bad_float, not_bitwise, worst = [], [], 0, 0.0
+    worst_by = {k: 0.0 for k in FLOATS}
+    nbit_by = {k: 0 for k in FLOATS}
     min_margin = 1e9
     for i, s in enumerate(seeds):
         r, g = refs[s], got[i]
@@ -102,14 +104,16 @@ def main():
         for k in FLOATS:
             x, y = float(g[k]), float(r[k])
             worst = max(worst, abs(x - y))
+            worst_by[k] = max(worst_by[k], abs(x - y))
             if abs(x - y) > 1e-5 + 1e-4 * abs(y):
                 bad_float.append((s, k, x, y))
             if np.float32(x) != np.float32(y):
                 not_bitwise += 1
+                nbit_by[k] += 1
     print(json.dumps({"songs": a.songs, "seed": a.seed, "int_mismatches": bad_int[:10],
                       "n_int_mismatches": len(bad_int), "float_out_of_tolerance": bad_float[:10],
                       "n_float_out_of_tolerance": len(bad_float), "float_fields_not_bit_identical": not_bitwise,
-                      "worst_abs_err": worst, "min_peak_margin": min_margin,
+                      "worst_abs_err": worst, "worst_abs_err_by_field": worst_by, "not_bit_identical_by_field": nbit_by, "min_peak_margin": min_margin,
                       "gpu_seconds_incl_synthesis_and_upload": round(t1 - t0, 2),
                       "oracle_seconds": round(t2 - t1, 2), "procs": a.procs or os.cpu_count()}))
     return 1 if (bad_int or bad_float) else 0
