@@ -13,14 +13,14 @@
  *                  the normalisation            ref src/tempo_atk_sort.c:101-107
  *   k_variance_wrap  exact int32-wrapping bl_variance for |mean| > 13571
  *   k_amp_finish   301-pass smoothing + integral ref src/amplitude_sort.c:41-79
- *   k_freq_frames  Hann + 512-pt f32 real DFT power, summed over frames
- *                                               ref src/frequency_sort.c:67-94
+ *   k_freq_frames  Hann + 512-pt f32 real DFT power, summed over the frames in the
+ *                  reference's order            ref src/frequency_sort.c:67-94
  *   k_freq_finish  dB spectrum, 5 bands, score  ref src/frequency_sort.c:97-139
- *   k_env_windows  normalise, 17-tap FIR, 512-pt f64 real DFT, f32-rounded
+ *   k_env_windows2 normalise, 17-tap FIR, 512-pt f64 real DFT, f32-rounded
  *                  energy per window            ref src/tempo_atk_sort.c:109-153
- *   k_env_tail     log-compress, IIR, box filters, peaks, tempo/attack, force
- *                                               ref src/tempo_atk_sort.c:184-284,
- *                                               src/analyze.c:63-80
+ *   k_env_tail     IIR, box filters, peaks, tempo/attack
+ *                                               ref src/tempo_atk_sort.c:184-284
+ *   k_force        force, calm_or_loud          ref src/analyze.c:63-80
  *   k_pairwise     bl_distance / bl_cosine_similarity matrix
  *                                               ref src/analyze.c:96-100,135-140
  *   k_synth        integer synthetic PCM (benchmark corpus)
@@ -501,14 +501,13 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
   spectrum[(size_t)blockIdx.x * 256 + tid] = accv[tid];
 }
 
-__global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ partial,
+__global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ spectrum,
                                                      const bl_dsong *__restrict__ songs,
                                                      bl_amd_song_result *res) {
   __shared__ float ps[256];
   __shared__ float wmax[4];
   const int d = threadIdx.x, song = blockIdx.x;
-  float acc = 0.f;
-  acc = partial[(size_t)song * 256 + d];
+  const float acc = spectrum[(size_t)song * 256 + d];
   /* ref :97-102: sqrt(ps / 512), peak over d = 1..256 (ps[256] is 0) */
   float v = d == 0 ? 0.f : (float)sqrt((double)(acc / 512));
   float m = v;
@@ -710,9 +709,6 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   double *buf = reinterpret_cast<double *>(smem) + wave * EV2_SLOTS;
   const int mean = st.mean;
   const double vprime = st.vprime, rcp = st.rcp;
-  /* the wave's 1280 samples of a round are 160 16-byte chunks: lane ln owns chunks ln,
-   * ln + 64 and (ln < 32) ln + 128; they are fetched one round ahead so that the HBM
-   * latency hides behind the arithmetic of the current round */
   /* lane ln owns samples 20*ln .. 20*ln+19 of the wave's 1280 (five 8-byte loads) plus
    * the one sample that starts its own zero-state output (lane (g, l): sample l of window
    * g); both are fetched one round ahead so that the HBM latency hides behind the
