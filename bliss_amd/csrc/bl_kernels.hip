@@ -1151,6 +1151,8 @@ struct Ctx {
   int env_dbg = 0;
   hipStream_t side = nullptr; /* envelope tail runs here, beside the frequency pass */
   hipEvent_t ev_env = nullptr, ev_tail = nullptr;
+  hipEvent_t ev_ws = nullptr; /* end of the last launch group that used the shared workspace */
+  bool ws_used = false;
   bool side_ok = false;
   long long last_env_total = 0;
   int device = 0;
@@ -1243,6 +1245,7 @@ int init_locked(int device) {
     BL_HIP_CHECK(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
     BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_env, hipEventDisableTiming));
     BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_tail, hipEventDisableTiming));
+    BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_ws, hipEventDisableTiming));
     g.side_ok = true;
   }
   g.device = device;
@@ -1347,6 +1350,9 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   const int max_frames = (max_n / 512);
   const int gx_scan = grid_x_for(((long long)max_n / 8 + 255) / 256, n_songs, 8);
 
+  /* the scratch buffers below are shared by every call: a batch enqueued on another stream
+   * waits (on the device) for the previous user; the host-side mutex only orders the enqueues */
+  if (g.ws_used) BL_HIP_CHECK(hipStreamWaitEvent(stream, g.ev_ws, 0));
   if (ensure(g.songs, sizeof(bl_dsong) * n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.stats, sizeof(bl_dstats) * n_songs) != BL_OK) return BL_UNEXPECTED;
   if (ensure(g.hist, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
@@ -1437,6 +1443,8 @@ int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_so
   if (tail_async) BL_HIP_CHECK(hipStreamWaitEvent(stream, g.ev_tail, 0));
   if (what == 7) hipLaunchKernelGGL(k_force, dim3(tb64), dim3(64), 0, stream, d_results, n_songs);
   BL_HIP_CHECK(hipGetLastError());
+  BL_HIP_CHECK(hipEventRecord(g.ev_ws, stream));
+  g.ws_used = true;
   return BL_OK;
 }
 
@@ -1842,6 +1850,8 @@ void bl_amd_shutdown(void) {
     (void)hipStreamDestroy(g.side);
     (void)hipEventDestroy(g.ev_env);
     (void)hipEventDestroy(g.ev_tail);
+    (void)hipEventDestroy(g.ev_ws);
+    g.ws_used = false;
     g.side_ok = false;
   }
   g.ready = false;

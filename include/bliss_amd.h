@@ -61,7 +61,9 @@ int bl_amd_device_count(void);
 /* Analyse n_songs songs whose PCM already sits in device memory.
  * d_pcm: arena base; h_desc: host array of n_songs descriptors;
  * d_results: device array of n_songs results (written asynchronously on
- * `stream`).  Scratch comes from an internal, growing device workspace. */
+ * `stream`).  Scratch comes from an internal, growing device workspace that all calls
+ * share: batches enqueued on different streams are ordered on the device (each waits
+ * for the previous one to finish with the workspace), they do not overlap. */
 int bl_amd_analyze_batch_device(const int16_t *d_pcm, const bl_amd_song_desc *h_desc,
                                 int n_songs, bl_amd_song_result *d_results, void *stream);
 

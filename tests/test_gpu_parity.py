@@ -372,3 +372,30 @@ def test_c_caller_links_and_passes(gpu_lib, tmp_path):
                     "-Wl,-rpath," + os.path.join(root, "bliss_amd")], check=True)
     r = subprocess.run([exe, os.path.join(HERE, "golden", "song.flac")], stdout=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_batches_on_two_streams_do_not_race(gpu_lib, oracle):
+    """The library's scratch workspace is shared by all calls: two device-resident batches enqueued back
+    to back on different HIP streams must still give each its own results (device-side ordering through
+    an event, not only the host mutex)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    pcm_a = [oracle.synth(700 + i, 22050, 2, 22050 * 2 * 8) for i in range(6)]
+    pcm_b = [oracle.synth(800 + i, 22050, 1, 22050 * 9) for i in range(6)]
+    ca = bliss_amd.DeviceCorpus([p.size for p in pcm_a], 2, 8)
+    cb = bliss_amd.DeviceCorpus([p.size for p in pcm_b], 1, 9)
+    for i in range(6):
+        ca.upload(i, pcm_a[i])
+        cb.upload(i, pcm_b[i])
+    torch.cuda.synchronize(dev)
+    for _ in range(3):  # several rounds of interleaved enqueues
+        with torch.cuda.stream(s1):
+            ca.analyze()
+        with torch.cuda.stream(s2):
+            cb.analyze()
+    torch.cuda.synchronize(dev)
+    ra, rb = ca.fetch(), cb.fetch()
+    for i in range(6):
+        check_song(ra[i], oracle.analyze(pcm_a[i], 2, 8), ("stream1", i))
+        check_song(rb[i], oracle.analyze(pcm_b[i], 1, 9), ("stream2", i))
