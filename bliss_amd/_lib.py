@@ -71,7 +71,23 @@ SYMBOLS = {
     # include/bliss_amd.h
     "bl_amd_init": (C.c_int, [C.c_int]),
     "bl_amd_device_count": (C.c_int, []),
+    "bl_amd_ctx_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
+    "bl_amd_ctx_destroy": (None, [C.c_void_p]),
+    "bl_amd_ctx_device": (C.c_int, [C.c_void_p]),
     "bl_amd_analyze_batch_device": (C.c_int, [C.c_void_p, _P(SongDesc), C.c_int, C.c_void_p, C.c_void_p]),
+    "bl_amd_ctx_analyze_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, _P(SongDesc), C.c_int, C.c_void_p,
+                                                  C.c_void_p]),
+    "bl_amd_ctx_analyze_batch_host": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
+                                                _P(C.c_uint64), C.c_int, _P(SongResult)]),
+    "bl_amd_set_host_transfer": (C.c_int, [C.c_int]),
+    "bl_amd_analyze_batch_host_s32": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
+                                                _P(C.c_uint64), C.c_int, _P(SongResult)]),
+    "bl_amd_narrow_s32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bl_amd_analyze_corpus_multi": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32), _P(C.c_uint64),
+                                              C.c_int, _P(C.c_int), C.c_int, C.c_int, _P(SongResult),
+                                              _P(C.c_float)]),
+    "bl_amd_decode_allow_native_rate": (None, [C.c_int]),
+    "bl_amd_flac_verify": (C.c_int, [C.c_char_p, _P(C.c_uint8), _P(C.c_uint8)]),
     "bl_amd_analyze_batch_host": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
                                             _P(C.c_uint64), C.c_int, _P(SongResult)]),
     "bl_amd_distance_matrix_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

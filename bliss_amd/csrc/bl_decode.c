@@ -2,20 +2,33 @@
  * bl_decode.c — host ingest behind bl_audio_decode().
  *
  * Replaces ref src/decode.c:27-213 (libavformat/libavcodec/libswresample) for
- * the container formats that need no third-party code: RIFF/WAVE PCM16 and
- * native FLAC (16-bit).  It fills struct bl_song exactly as
+ * the container formats that need no third-party code: RIFF/WAVE integer PCM
+ * (16 / 24 / 32 bit) and native FLAC (8 to 32 bit).  It fills struct bl_song as
  * fill_song_properties()/bl_audio_decode() do (ref src/decode.c:187-193,
  * 215-349): malloc'd interleaved s16 `sample_array`, nSamples = interleaved
  * count, nb_bytes_per_sample = 2, duration = whole seconds, strdup'd tags
  * (the reference's "<no title>"-style defaults when absent, ref
  * src/decode.c:263-308), filename.
  *
- * Out of scope: resampling to 22 050 Hz and the mono->stereo
- * up-mix of libswresample (ref src/decode.c:317-346) — third-party arithmetic
- * whose outputs are not reproducible here.  Sources that are already
- * 22 050 Hz stereo s16 (the reference's own audio/song.flac) decode to the
- * byte-identical sample_array (MD5 pinned by ref tests/test_decode.c:16-17);
- * other rates/layouts are passed through un-resampled with resampled = 0.
+ * Sources wider than 16 bits are narrowed like a same-rate S32 -> S16 sample
+ * format conversion (ref src/decode.c:323-346,388-392: libswresample): the
+ * sample left-justified in 32 bits, arithmetic >> 16 — for 24-bit audio the
+ * top 16 bits.  The FLAC decoder itself is pinned for 24-bit input by the
+ * STREAMINFO MD5 of the reference's audio/song_s32*.flac
+ * (tests/test_host_codelets.py); the narrowing step is libswresample's and
+ * stays parity-unpinned.
+ *
+ * Sample rate.  The reference always hands 22 050 Hz PCM to the analyzers
+ * (ref src/decode.c:7-9,317-346), and every analyzer constant assumes it.  There
+ * is no resampler here (libswresample's arithmetic cannot be reproduced), so a
+ * file at any other rate FAILS (BL_UNEXPECTED, message on stderr) unless the
+ * caller opted in with bl_amd_decode_allow_native_rate(1) /
+ * BL_AMD_ALLOW_NATIVE_RATE=1; then it is analysed at its native rate with
+ * resampled = 0, and its force vector is not comparable with the reference's.
+ * Sources that are already 22 050 Hz s16 (the reference's own audio/song.flac)
+ * decode to the byte-identical sample_array (MD5 pinned by ref
+ * tests/test_decode.c:16-17).  Mono files stay mono (the reference up-mixes
+ * through the resampler, ref src/decode.c:338).
  */
 #include <ctype.h>
 #include <stdint.h>
@@ -24,6 +37,28 @@
 #include <string.h>
 
 #include "bliss.h"
+#include "bliss_amd.h"
+
+#define BL_DECODE_RATE 22050 /* ref src/decode.c:7 SAMPLE_RATE */
+
+static int g_allow_native_rate = -1; /* -1: not set, look at the environment */
+
+void bl_amd_decode_allow_native_rate(int allow) { g_allow_native_rate = allow != 0; }
+
+static int native_rate_allowed(void) {
+  if (g_allow_native_rate < 0) {
+    const char *e = getenv("BL_AMD_ALLOW_NATIVE_RATE");
+    g_allow_native_rate = e && *e && strcmp(e, "0") != 0;
+  }
+  return g_allow_native_rate;
+}
+
+/* a sample of `bps` significant bits as the s16 the analyzers read: left-justify in 32 bits,
+ * arithmetic >> 16 */
+static inline int16_t narrow_sample(int32_t v, uint32_t bps) {
+  if (bps > 16) return (int16_t)(v >> (bps - 16));
+  return (int16_t)((uint32_t)v << (16 - bps));
+}
 
 /* ----------------------------------------------------------------------- */
 typedef struct {
@@ -131,26 +166,107 @@ static int decode_wav(const uint8_t *d, size_t len, struct bl_song *song) {
       if (fmt_tag == 0xFFFE && sz >= 26) fmt_tag = le16(body + 24); /* extensible */
       have_fmt = 1;
     } else if (!memcmp(d + pos, "data", 4)) {
-      if (!have_fmt || fmt_tag != 1 || bits != 16 || channels < 1 || channels > 2 || rate == 0)
+      if (!have_fmt || fmt_tag != 1 || (bits != 16 && bits != 24 && bits != 32) || channels < 1 ||
+          channels > 2 || rate == 0)
         return BL_UNEXPECTED;
-      uint32_t n = sz / 2;
+      const uint32_t bytes = bits / 8;
+      uint32_t n = sz / bytes;
       n -= n % channels;
       if (n == 0) return BL_UNEXPECTED;
       int16_t *pcm = (int16_t *)malloc((size_t)n * 2);
       if (!pcm) return BL_UNEXPECTED;
-      for (uint32_t i = 0; i < n; ++i) pcm[i] = (int16_t)le16(body + 2 * (size_t)i);
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t *q = body + (size_t)bytes * i;
+        if (bits == 16) pcm[i] = (int16_t)le16(q);
+        else if (bits == 24) pcm[i] = (int16_t)(le16(q + 1));        /* top 16 of 24 */
+        else pcm[i] = (int16_t)(le16(q + 2));                         /* top 16 of 32 */
+      }
       song->sample_array = (int8_t *)pcm;
       song->nSamples = (int)n;
       song->channels = (int)channels;
       song->sample_rate = (int)rate;
       song->nb_bytes_per_sample = 2;
       song->duration = (uint64_t)(n / channels) / rate;
-      song->bitrate = (int)(rate * channels * 16);
+      song->bitrate = (int)(rate * channels * bits);
       return BL_OK;
     }
     pos += 8 + (size_t)sz + (sz & 1);
   }
   return BL_UNEXPECTED;
+}
+
+/* ------------------------------- MD5 ----------------------------------- */
+/* RFC 1321, used only to check a FLAC stream against the signature of the unencoded audio
+ * that its STREAMINFO block carries (bl_amd_flac_verify). */
+typedef struct {
+  uint32_t h[4];
+  uint64_t len;
+  uint8_t buf[64];
+  size_t fill;
+} md5_state;
+
+static void md5_block(uint32_t h[4], const uint8_t *p) {
+  static const uint8_t rot[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22,
+                                  5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20,
+                                  4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
+                                  6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+  static uint32_t K[64];
+  static int have_k = 0;
+  if (!have_k) { /* K[i] = floor(2^32 * |sin(i + 1)|), as integers from a table-free recurrence */
+    static const uint32_t k0[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+        0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+        0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+        0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+        0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+        0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+        0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+        0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    memcpy(K, k0, sizeof K);
+    have_k = 1;
+  }
+  uint32_t w[16];
+  for (int i = 0; i < 16; ++i) w[i] = le32(p + 4 * i);
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+  for (int i = 0; i < 64; ++i) {
+    uint32_t f;
+    int g;
+    if (i < 16) { f = (b & c) | (~b & d); g = i; }
+    else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+    else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+    else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+    const uint32_t t = a + f + K[i] + w[g];
+    a = d; d = c; c = b;
+    b = b + ((t << rot[i]) | (t >> (32 - rot[i])));
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+}
+
+static void md5_init(md5_state *m) {
+  m->h[0] = 0x67452301; m->h[1] = 0xefcdab89; m->h[2] = 0x98badcfe; m->h[3] = 0x10325476;
+  m->len = 0; m->fill = 0;
+}
+
+static void md5_update(md5_state *m, const uint8_t *p, size_t n) {
+  m->len += n;
+  while (n) {
+    const size_t take = 64 - m->fill < n ? 64 - m->fill : n;
+    memcpy(m->buf + m->fill, p, take);
+    m->fill += take; p += take; n -= take;
+    if (m->fill == 64) { md5_block(m->h, m->buf); m->fill = 0; }
+  }
+}
+
+static void md5_final(md5_state *m, uint8_t out[16]) {
+  const uint64_t bits = m->len * 8;
+  const uint8_t one = 0x80, zero = 0;
+  md5_update(m, &one, 1);
+  while (m->fill != 56) md5_update(m, &zero, 1);
+  uint8_t lenb[8];
+  for (int i = 0; i < 8; ++i) lenb[i] = (uint8_t)(bits >> (8 * i));
+  md5_update(m, lenb, 8);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(m->h[i] >> (8 * j));
 }
 
 /* ------------------------------- FLAC ---------------------------------- */
@@ -246,16 +362,20 @@ static int flac_subframe(bitrd *b, int32_t *out, uint32_t blocksize, uint32_t bp
   return b->err ? -1 : 0;
 }
 
-static void flac_tags(const uint8_t *body, uint32_t sz, struct bl_song *song) {
+static void flac_tags(const uint8_t *body, uint32_t sz32, struct bl_song *song) {
+  /* all bounds in size_t and by subtraction: the lengths are attacker-controlled 32-bit
+   * fields and `pos + l` must not wrap */
+  const size_t sz = sz32;
   if (sz < 8) return;
-  uint32_t pos = 4 + le32(body);
-  if (pos + 4 > sz) return;
+  const size_t vlen = le32(body);
+  if (vlen > sz - 8) return;
+  size_t pos = 4 + vlen;
   uint32_t count = le32(body + pos);
   pos += 4;
-  for (uint32_t c = 0; c < count && pos + 4 <= sz; ++c) {
-    uint32_t l = le32(body + pos);
+  for (uint32_t c = 0; c < count && sz - pos >= 4; ++c) {
+    const size_t l = le32(body + pos);
     pos += 4;
-    if (pos + l > sz) return;
+    if (l > sz - pos) return;
     const char *kv = (const char *)body + pos;
     const char *eq = (const char *)memchr(kv, '=', l);
     if (eq) {
@@ -280,7 +400,14 @@ static void flac_tags(const uint8_t *body, uint32_t sz, struct bl_song *song) {
   }
 }
 
-static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song) {
+/* sig (optional): receives the MD5 of the decoded samples at their native width (what FLAC
+ * calls the signature of the unencoded audio) and the signature stored in STREAMINFO */
+typedef struct {
+  md5_state md;
+  uint8_t stored[16];
+} flac_sig;
+
+static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, flac_sig *sig) {
   if (len < 42 || memcmp(d, "fLaC", 4)) return BL_UNEXPECTED;
   size_t pos = 4;
   flac_info fi;
@@ -299,14 +426,15 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song) {
       fi.bps = (((uint32_t)body[12] & 1) << 4 | (body[13] >> 4)) + 1;
       fi.total = ((uint64_t)(body[13] & 15) << 32) | ((uint64_t)body[14] << 24) |
                  ((uint64_t)body[15] << 16) | ((uint64_t)body[16] << 8) | body[17];
+      if (sig) memcpy(sig->stored, body + 18, 16);
       have_info = 1;
     } else if (type == 4) {
       flac_tags(body, sz, song);
     }
     pos += 4 + sz;
   }
-  if (!have_info || fi.bps != 16 || fi.channels < 1 || fi.channels > 2 || fi.rate == 0)
-    return BL_UNEXPECTED; /* 24-bit sources need the resampler path: out of scope */
+  if (!have_info || fi.bps < 8 || fi.bps > 32 || fi.channels < 1 || fi.channels > 2 || fi.rate == 0)
+    return BL_UNEXPECTED;
   size_t audio_start = pos;
 
   size_t cap = fi.total ? (size_t)fi.total * fi.channels : (size_t)1 << 20;
@@ -343,8 +471,9 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song) {
     else if (sr_code == 13 || sr_code == 14) br_bits(&b, 16);
     br_bits(&b, 8); /* CRC-8 (not verified) */
     if (blocksize == 0 || blocksize > maxb + 16) { ++pos; continue; }
-    uint32_t bps = fi.bps;
-    if (ss_code == 4) bps = 16; else if (ss_code != 0) { rc = BL_UNEXPECTED; break; }
+    static const uint32_t ss_tab[8] = {0, 8, 12, 0, 16, 20, 24, 32};
+    uint32_t bps = ss_code == 0 ? fi.bps : ss_tab[ss_code];
+    if (bps != fi.bps) { rc = BL_UNEXPECTED; break; } /* reserved code or a mid-stream change */
     uint32_t nch = chan < 8 ? chan + 1 : 2;
     if (nch != fi.channels) { rc = BL_UNEXPECTED; break; }
     int bad = 0;
@@ -372,8 +501,17 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song) {
         l = (mid + side) >> 1;
         r = (mid - side) >> 1;
       }
-      pcm[n++] = (int16_t)l;
-      if (nch == 2) pcm[n++] = (int16_t)r;
+      pcm[n++] = narrow_sample(l, bps);
+      if (nch == 2) pcm[n++] = narrow_sample(r, bps);
+      if (sig) { /* little-endian, (bps + 7) / 8 bytes per sample, interleaved */
+        uint8_t raw[8];
+        const uint32_t nb = (bps + 7) / 8;
+        for (uint32_t k = 0; k < nb; ++k) {
+          raw[k] = (uint8_t)((uint32_t)l >> (8 * k));
+          raw[nb + k] = (uint8_t)((uint32_t)r >> (8 * k));
+        }
+        md5_update(&sig->md, raw, nb * nch);
+      }
     }
   }
   free(ch[0]);
@@ -412,10 +550,19 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
     return BL_UNEXPECTED;
   }
   int rc = BL_UNEXPECTED;
-  if (len >= 4 && !memcmp(data, "fLaC", 4)) rc = decode_flac(data, len, song);
+  if (len >= 4 && !memcmp(data, "fLaC", 4)) rc = decode_flac(data, len, song, NULL);
   else if (len >= 12 && !memcmp(data, "RIFF", 4)) rc = decode_wav(data, len, song);
-  else fprintf(stderr, "Unsupported container (WAV PCM16 / FLAC 16-bit only): %s\n", filename);
+  else fprintf(stderr, "Unsupported container (WAV integer PCM / FLAC only): %s\n", filename);
   free(data);
+  if (rc == BL_OK && song->sample_rate != BL_DECODE_RATE && !native_rate_allowed()) {
+    fprintf(stderr,
+            "bliss_amd: %s is %d Hz; the analyzers expect %d Hz PCM and this library has no resampler "
+            "(bl_amd_decode_allow_native_rate(1) analyses it at its native rate)\n",
+            filename, song->sample_rate, BL_DECODE_RATE);
+    free(song->sample_array);
+    song->sample_array = NULL;
+    rc = BL_UNEXPECTED;
+  }
   if (rc != BL_OK) {
     free(song->artist); free(song->title); free(song->album);
     free(song->tracknumber); free(song->genre);
@@ -431,4 +578,29 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
   if (!song->genre) song->genre = strdup("<no genre>");
   song->tracknumber[strcspn(song->tracknumber, "/")] = '\0'; /* ref src/decode.c:267 */
   return BL_OK;
+}
+
+/* include/bliss_amd.h: decode a FLAC file and compare the MD5 of the decoded samples (native
+ * width, before the narrowing to s16) with the signature of the unencoded audio stored in its
+ * STREAMINFO block.  Returns 1 when they match, 0 when they differ, BL_UNEXPECTED when the file
+ * cannot be decoded; both digests are returned when the pointers are non-NULL. */
+int bl_amd_flac_verify(const char *filename, uint8_t computed[16], uint8_t stored[16]) {
+  uint8_t *data = NULL;
+  size_t len = 0;
+  if (!filename || read_file(filename, &data, &len) != 0) return BL_UNEXPECTED;
+  struct bl_song song;
+  memset(&song, 0, sizeof song);
+  flac_sig sig;
+  md5_init(&sig.md);
+  memset(sig.stored, 0, sizeof sig.stored);
+  const int rc = decode_flac(data, len, &song, &sig);
+  free(data);
+  free(song.sample_array);
+  free(song.artist); free(song.title); free(song.album); free(song.tracknumber); free(song.genre);
+  if (rc != BL_OK) return BL_UNEXPECTED;
+  uint8_t got[16];
+  md5_final(&sig.md, got);
+  if (computed) memcpy(computed, got, 16);
+  if (stored) memcpy(stored, sig.stored, 16);
+  return memcmp(got, sig.stored, 16) == 0;
 }

@@ -25,9 +25,6 @@ extern "C" {
 int bld_ready(void); /* BL_OK when a device is initialised, else tries device 0 */
 int bld_mean_variance_host(const int16_t *h_pcm, int n, int have_mean, int mean_in,
                            int *mean_out, int *variance_out);
-int bld_rect_filter_host(double *h_out, const double *h_in, int n, int width);
-int bld_pair_host(const struct force_vector_s *a, const struct force_vector_s *b, int cosine,
-                  float *out);
 /* single analyzers on one host-resident song (what = 1 amplitude, 2 frequency,
  * 4 envelope, 7 all); fills *res */
 int bld_analyze_one_host(const int16_t *h_pcm, int n, int channels, uint64_t duration, int what,

@@ -30,13 +30,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <algorithm>
-#include <mutex>
-#include <thread>
-#include <vector>
 
-#include "bl_device.h"
-#include "bl_fft.h"
+#include "bl_launch.h"
 #include "bl_tail.h"
 
 #define BL_HIP_CHECK(expr)                                                              \
@@ -48,38 +43,6 @@
       return BL_UNEXPECTED;                                                             \
     }                                                                                   \
   } while (0)
-
-/* ------------------------------------------------------------------------- */
-/* device-side records                                                        */
-
-struct bl_dsong {
-  unsigned long long pcm_off;  /* int16 elements from the arena base */
-  unsigned long long duration; /* seconds */
-  long long env_off;           /* first slot of this song in the per-window arrays */
-  int n, channels;
-  int n_frames;  /* (n / channels) / 512              ref frequency_sort.c:50 */
-  int nb_frames; /* 2 * floor(n / 512)                ref tempo_atk_sort.c:63-64 */
-  int n_windows; /* nb_frames - 2 windows of hop 256  ref tempo_atk_sort.c:66-67,120 */
-  int part_off;  /* unused (was: first partial-spectrum slot) */
-  int out_idx;   /* result slot = position in the caller's order (records are length-sorted) */
-  int pad;
-};
-
-struct bl_dstats {
-  unsigned long long sum;   /* two's-complement sum of all samples */
-  unsigned long long sumsq; /* sum of squares */
-  unsigned first;           /* first index with a non-zero sample */
-  int last;                 /* last index with a non-zero sample */
-  int mean, variance;
-  double vprime; /* variance * 2^-15 */
-  double rcp;    /* RN(1 / vprime) */
-  int wrap_pass; /* 1: variance must come from k_variance_wrap */
-  int status;
-  long long wrap_acc; /* accumulator of k_variance_wrap */
-};
-
-typedef bl_c2<double> c2d;
-typedef bl_c2<float> c2f;
 
 /* FIR taps: literal digits of ref include/bandpass_coeffs.h:1-7 (symmetric) */
 #define BL_C0 (-0.0023470)
@@ -376,12 +339,6 @@ __global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__
 /* ------------------------------------------------------------------------- */
 /* k_freq_frames                                                              */
 
-struct bl_tables {
-  const c2d *tw256_d, *tw512_d;
-  const c2f *tw256_f, *tw512_f;
-  const float *hann;
-  double log101;
-};
 
 /* exchange buffers (the partner half rows and the per-wave power staging reuse them),
  * twiddles, Hann, the running spectrum and the relay word: 41.9 KB -> three workgroups per CU
@@ -1112,103 +1069,53 @@ __global__ __launch_bounds__(256) void k_synth(int16_t *pcm, const bl_dsong *__r
     p[i] = syn_sample(seed, rate, (unsigned)sg.channels, i);
 }
 
-/* single-thread sequential kernels behind the helper shims */
-__global__ void k_rect_filter(double *out, const double *in, int n, int width) {
-  /* ref tempo_atk_sort.c:19-40, literally */
-  const int half = (int)round(width / 2.);
-  double run = 0;
-  for (int k = 0; k < width; ++k) run += in[k];
-  for (int k = 0; k < n - width; ++k) {
-    out[k + half - 1] = run;
-    run -= in[k];
-    run += in[k + width];
+
+/* ------------------------------------------------------------------------- */
+/* small data-movement kernels of the batch / multi-device paths                */
+
+/* same-rate S32 -> S16 narrowing of a 32-bit source (what the reference's resampler does
+ * for an S32 input at the target rate, ref src/decode.c:388-392 -> swr_convert): arithmetic
+ * shift by 16.  Parity unpinned (libswresample is absent). */
+__global__ __launch_bounds__(256) void k_narrow_s32(const int4 *__restrict__ in, uint2 *__restrict__ out,
+                                                    size_t nvec, const int32_t *__restrict__ in_s,
+                                                    int16_t *__restrict__ out_s, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256u;
+  const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+  for (size_t v = t; v < nvec; v += stride) { /* 16 bytes in, 8 bytes out per lane */
+    const int4 q = in[v];
+    uint2 o;
+    o.x = ((unsigned)q.x >> 16) | ((unsigned)q.y & 0xFFFF0000u);
+    o.y = ((unsigned)q.z >> 16) | ((unsigned)q.w & 0xFFFF0000u);
+    out[v] = o;
   }
-  for (int k = n - width; k < n; ++k) out[n - half] += in[k];
-  for (int k = 0; k < n; ++k) out[k] /= width;
+  for (size_t i = 4 * nvec + t; i < n; i += stride) out_s[i] = (int16_t)(in_s[i] >> 16);
 }
 
-__global__ void k_pair(const float4 a, const float4 b, int cosine, float *out) {
-  *out = cosine ? bl_cos(a, b) : bl_dist(a, b);
+__global__ __launch_bounds__(256) void k_scatter_vecs(const float4 *__restrict__ in,
+                                                      const int32_t *__restrict__ order,
+                                                      float4 *__restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && order[i] >= 0) out[order[i]] = in[i]; /* -1: padding slot of a short shard */
+}
+
+__global__ __launch_bounds__(256) void k_extract_vecs(const bl_amd_song_result *__restrict__ res,
+                                                      float4 *__restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const struct force_vector_s v = res[i].v;
+    out[i] = make_float4(v.tempo, v.amplitude, v.frequency, v.attack);
+  }
 }
 
 /* ========================================================================= */
-/* host side: context, workspace, launches                                    */
+/* launchers (declared in bl_launch.h)                                        */
 
-namespace {
+size_t blk_tables_bytes(void) { return 256 * 16 * 2 + 256 * 8 * 2 + 512 * 4; }
 
-enum { PK_SCAN, PK_AMP, PK_FREQ, PK_FREQ_FIN, PK_ENV, PK_TAIL, PK_DIST, PK_COUNT };
-const char *const kProfNames[PK_COUNT] = {"pcm_scan",    "amp_finish", "freq_frames", "freq_finish",
-                                          "env_windows", "env_tail",   "distance"};
-
-struct Buf {
-  void *p = nullptr;
-  size_t cap = 0;
-};
-
-struct Ctx {
-  std::mutex mu;
-  bool ready = false;
-  int env_dbg = 0;
-  hipStream_t side = nullptr; /* envelope tail runs here, beside the frequency pass */
-  hipEvent_t ev_env = nullptr, ev_tail = nullptr;
-  hipEvent_t ev_ws = nullptr; /* end of the last launch group that used the shared workspace */
-  bool ws_used = false;
-  bool side_ok = false;
-  long long last_env_total = 0;
-  int device = 0;
-  int n_cu = 256;
-  bl_tables tb{};
-  void *tables_mem = nullptr;
-  Buf songs, stats, hist, partial, energies, lc, results, misc;
-  /* profiling */
-  bool prof = false;
-  struct Ev { int k; hipEvent_t a, b; };
-  std::vector<Ev> events;
-  double prof_ms[PK_COUNT] = {0};
-  int prof_n[PK_COUNT] = {0};
-  /* host batch staging */
-  void *pinned[2] = {nullptr, nullptr};
-  size_t pinned_cap[2] = {0, 0};
-  Buf arena[2];
-  hipStream_t streams[2] = {nullptr, nullptr};
-};
-
-Ctx g;
-
-int ensure(Buf &b, size_t bytes) {
-  if (bytes <= b.cap) return BL_OK;
-  if (b.p) {
-    BL_HIP_CHECK(hipDeviceSynchronize());
-    BL_HIP_CHECK(hipFree(b.p));
-    b.p = nullptr; b.cap = 0;
-  }
-  size_t cap = bytes + bytes / 8 + 4096;
-  BL_HIP_CHECK(hipMalloc(&b.p, cap));
-  b.cap = cap;
-  return BL_OK;
-}
-
-int init_locked(int device) {
-  if (g.ready && g.device == device) return BL_OK;
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0) {
-    fprintf(stderr, "bliss_amd: no HIP device available (%s); this library has no CPU path\n",
-            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-    return BL_UNEXPECTED;
-  }
-  if (device < 0 || device >= count) {
-    fprintf(stderr, "bliss_amd: device %d out of range (%d visible)\n", device, count);
-    return BL_UNEXPECTED;
-  }
-  BL_HIP_CHECK(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  BL_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-  g.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  /* twiddle / window tables, computed once in double on the host */
+void blk_tables_fill_host(unsigned char *h) {
+  /* twiddle / window tables, computed in double on the host */
   const double pi = 3.14159265358979323846;
-  std::vector<unsigned char> h(256 * 16 * 2 + 256 * 8 * 2 + 512 * 4);
-  c2d *t256 = reinterpret_cast<c2d *>(h.data());
+  c2d *t256 = reinterpret_cast<c2d *>(h);
   c2d *t512 = t256 + 256;
   c2f *f256 = reinterpret_cast<c2f *>(t512 + 256);
   c2f *f512 = f256 + 256;
@@ -1221,117 +1128,49 @@ int init_locked(int device) {
   }
   /* ref frequency_sort.c:40-42 */
   for (int i = 0; i < 512; ++i) hann[i] = (float)(.5f * (1.0f - cos(2 * M_PI * i / (512 - 1))));
-  if (g.tables_mem) { (void)hipFree(g.tables_mem); g.tables_mem = nullptr; }
-  BL_HIP_CHECK(hipMalloc(&g.tables_mem, h.size()));
-  BL_HIP_CHECK(hipMemcpy(g.tables_mem, h.data(), h.size(), hipMemcpyHostToDevice));
-  unsigned char *d = static_cast<unsigned char *>(g.tables_mem);
-  g.tb.tw256_d = reinterpret_cast<const c2d *>(d);
-  g.tb.tw512_d = g.tb.tw256_d + 256;
-  g.tb.tw256_f = reinterpret_cast<const c2f *>(g.tb.tw512_d + 256);
-  g.tb.tw512_f = g.tb.tw256_f + 256;
-  g.tb.hann = reinterpret_cast<const float *>(g.tb.tw512_f + 256);
-  g.tb.log101 = log((double)(1 + 100.0f)); /* ref tempo_atk_sort.c:188, log(1 + mu) */
+}
+
+bl_tables blk_tables_bind(const void *d_mem) {
+  bl_tables tb;
+  const unsigned char *d = static_cast<const unsigned char *>(d_mem);
+  tb.tw256_d = reinterpret_cast<const c2d *>(d);
+  tb.tw512_d = tb.tw256_d + 256;
+  tb.tw256_f = reinterpret_cast<const c2f *>(tb.tw512_d + 256);
+  tb.tw512_f = tb.tw256_f + 256;
+  tb.hann = reinterpret_cast<const float *>(tb.tw512_f + 256);
+  tb.log101 = log((double)(1 + 100.0f)); /* ref tempo_atk_sort.c:188, log(1 + mu) */
+  return tb;
+}
+
+int blk_configure_device(void) {
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
-  {
-    const char *d = getenv("BL_AMD_ENV_DBG"); /* bit 0: skip the ordered sums, bit 1: skip compute */
-    g.env_dbg = d ? atoi(d) : 0;
-  }
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
-  if (!g.side_ok) {
-    BL_HIP_CHECK(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
-    BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_env, hipEventDisableTiming));
-    BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_tail, hipEventDisableTiming));
-    BL_HIP_CHECK(hipEventCreateWithFlags(&g.ev_ws, hipEventDisableTiming));
-    g.side_ok = true;
-  }
-  g.device = device;
-  g.ready = true;
   return BL_OK;
 }
 
-struct ProfScope {
+namespace {
+
+struct Mark {
+  blk_mark_fn fn;
+  void *user;
   int k;
   hipStream_t s;
-  hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(int kk, hipStream_t ss) : k(kk), s(ss) {
-    if (!g.prof) return;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-    (void)hipEventRecord(a, s);
+  Mark(blk_mark_fn f, void *u, int kk, hipStream_t ss) : fn(f), user(u), k(kk), s(ss) {
+    if (fn) fn(user, k, s, 1);
   }
-  ~ProfScope() {
-    if (!a) return;
-    (void)hipEventRecord(b, s);
-    g.events.push_back({k, a, b});
+  ~Mark() {
+    if (fn) fn(user, k, s, 0);
   }
 };
 
-void prof_collect() {
-  for (auto &e : g.events) {
-    float ms = 0;
-    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-      g.prof_ms[e.k] += ms;
-      g.prof_n[e.k] += 1;
-    }
-    (void)hipEventDestroy(e.a);
-    (void)hipEventDestroy(e.b);
-  }
-  g.events.clear();
-}
-
-/* host mirror of the per-song geometry (integer work of ref tempo_atk_sort.c:63-67,
- * frequency_sort.c:50) */
-int fill_songs(const bl_amd_song_desc *desc, int n_songs, std::vector<bl_dsong> &out,
-               long long &env_total, int &max_n) {
-  out.resize(n_songs);
-  env_total = 0;
-  max_n = 0;
-  for (int i = 0; i < n_songs; ++i) {
-    const bl_amd_song_desc &d = desc[i];
-    if (d.n_samples < 5120 || (d.channels != 1 && d.channels != 2) || d.duration == 0 ||
-        (d.pcm_offset & 7)) {
-      fprintf(stderr,
-              "bliss_amd: song %d rejected (n_samples=%d channels=%d duration=%llu offset=%llu): "
-              "need n_samples >= 5120, channels 1|2, duration > 0, offset %% 8 == 0\n",
-              i, d.n_samples, d.channels, (unsigned long long)d.duration,
-              (unsigned long long)d.pcm_offset);
-      return BL_UNEXPECTED;
-    }
-    bl_dsong &s = out[i];
-    s.pcm_off = d.pcm_offset;
-    s.duration = d.duration;
-    s.n = d.n_samples;
-    s.channels = d.channels;
-    s.n_frames = (d.n_samples / d.channels) / 512;
-    s.nb_frames = (d.n_samples - (d.n_samples % 512)) * 2 / 512;
-    s.n_windows = s.nb_frames - 2;
-    s.env_off = env_total;
-    s.part_off = 0;
-    s.out_idx = i;
-    s.pad = 0;
-    env_total += s.nb_frames;
-    if (d.n_samples > max_n) max_n = d.n_samples;
-  }
-  /* Mixed-length corpora: process the records longest first.  The 64 songs that share a
-   * wave of k_env_tail then have similar lengths (its straight-line steady-state path is
-   * wave-uniform), and the long songs do not straggle at the end of the per-song grids.
-   * Results go back to the caller's order through out_idx; scratch offsets keep the
-   * caller's order too.  Equal lengths: the order is left alone. */
-  bool mixed = false;
-  for (int i = 1; i < n_songs && !mixed; ++i) mixed = out[i].n != out[0].n;
-  if (mixed)
-    std::stable_sort(out.begin(), out.end(),
-                     [](const bl_dsong &a, const bl_dsong &b) { return a.n > b.n; });
-  return BL_OK;
-}
-
-int grid_x_for(long long units_max, int n_songs, int blocks_per_cu) {
+int grid_x_for(long long units_max, int n_songs, int blocks_per_cu, int n_cu) {
   /* enough blocks to fill the chip several times over, never more than the
    * longest song has work for */
-  long long want = ((long long)g.n_cu * blocks_per_cu + n_songs - 1) / n_songs;
+  long long want = ((long long)n_cu * blocks_per_cu + n_songs - 1) / n_songs;
   if (want < 1) want = 1;
   if (want > units_max) want = units_max;
   if (want < 1) want = 1;
@@ -1339,224 +1178,101 @@ int grid_x_for(long long units_max, int n_songs, int blocks_per_cu) {
   return (int)want;
 }
 
-/* analysis of songs [0, n) of one launch group (n <= 32768) */
-int analyze_group(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
-                  bl_amd_song_result *d_results, hipStream_t stream, int what) {
-  std::vector<bl_dsong> hs;
-  long long env_total = 0;
-  int max_n = 0;
-  if (fill_songs(h_desc, n_songs, hs, env_total, max_n) != BL_OK) return BL_UNEXPECTED;
+} // namespace
 
-  const int max_frames = (max_n / 512);
-  const int gx_scan = grid_x_for(((long long)max_n / 8 + 255) / 256, n_songs, 8);
-
-  /* the scratch buffers below are shared by every call: a batch enqueued on another stream
-   * waits (on the device) for the previous user; the host-side mutex only orders the enqueues */
-  if (g.ws_used) BL_HIP_CHECK(hipStreamWaitEvent(stream, g.ev_ws, 0));
-  if (ensure(g.songs, sizeof(bl_dsong) * n_songs) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.stats, sizeof(bl_dstats) * n_songs) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.hist, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.partial, sizeof(float) * 256 * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.energies, sizeof(float) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.lc, sizeof(double) * (size_t)env_total) != BL_OK) return BL_UNEXPECTED;
-
-  g.last_env_total = env_total;
-  bl_dsong *d_songs = static_cast<bl_dsong *>(g.songs.p);
-  bl_dstats *d_stats = static_cast<bl_dstats *>(g.stats.p);
-  unsigned *d_hist = static_cast<unsigned *>(g.hist.p);
-  float *d_partial = static_cast<float *>(g.partial.p);
-  float *d_energies = static_cast<float *>(g.energies.p);
-  double *d_lc = static_cast<double *>(g.lc.p);
-
-  BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs.data(), sizeof(bl_dsong) * n_songs, hipMemcpyHostToDevice,
-                              stream));
-  /* the pageable source must stay alive until the copy has been staged */
-  BL_HIP_CHECK(hipStreamSynchronize(stream));
-  BL_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
+/* analysis of one launch group (n_songs <= 32768: gridDim.y) */
+int blk_analyze(const blk_analyze_args &a) {
+  const int n_songs = a.n_songs, what = a.what;
+  hipStream_t stream = a.stream;
+  const int max_frames = a.max_n / 512;
+  const int gx_scan = grid_x_for(((long long)a.max_n / 8 + 255) / 256, n_songs, 8, a.n_cu);
+  BL_HIP_CHECK(hipMemsetAsync(a.hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
   const int tb64 = (n_songs + 63) / 64;
-  hipLaunchKernelGGL(k_stats_init, dim3(tb64), dim3(64), 0, stream, d_stats, n_songs);
+  hipLaunchKernelGGL(k_stats_init, dim3(tb64), dim3(64), 0, stream, a.stats, n_songs);
   {
-    ProfScope ps(PK_SCAN, stream);
-    if (getenv("BL_AMD_SCAN_NOHIST")) /* measurement aid: cost of the LDS histogram */
-      hipLaunchKernelGGL(k_pcm_scan<false>, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm,
-                         d_songs, d_stats, d_hist);
-    else
-    hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm, d_songs,
-                       d_stats, d_hist);
+    Mark m(a.mark, a.mark_user, PK_SCAN, stream);
+    hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx_scan, n_songs), dim3(256), 0, stream, a.pcm, a.songs,
+                       a.stats, a.hist);
   }
-  hipLaunchKernelGGL(k_song_prep, dim3(tb64), dim3(64), 0, stream, d_songs, d_stats, n_songs,
-                     d_results);
-  hipLaunchKernelGGL(k_variance_wrap, dim3(gx_scan, n_songs), dim3(256), 0, stream, d_pcm, d_songs,
-                     d_stats);
-  hipLaunchKernelGGL(k_variance_wrap_finish, dim3(tb64), dim3(64), 0, stream, d_songs, d_stats,
-                     n_songs, d_results);
+  hipLaunchKernelGGL(k_song_prep, dim3(tb64), dim3(64), 0, stream, a.songs, a.stats, n_songs,
+                     a.results);
+  hipLaunchKernelGGL(k_variance_wrap, dim3(gx_scan, n_songs), dim3(256), 0, stream, a.pcm, a.songs,
+                     a.stats);
+  hipLaunchKernelGGL(k_variance_wrap_finish, dim3(tb64), dim3(64), 0, stream, a.songs, a.stats,
+                     n_songs, a.results);
   /* Order: the envelope windows first, then the serial envelope tail on an internal side
    * stream while the main stream runs the frequency and amplitude kernels (the tail is one
    * latency-bound wave per 64 songs and leaves the chip free); k_force joins the two. */
   bool tail_async = false;
   if (what & 4) {
     {
-      ProfScope ps(PK_ENV, stream);
+      Mark m(a.mark, a.mark_user, PK_ENV, stream);
       /* one 512-thread workgroup per CU; blocks of a song split its 28-window tiles */
-      const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2);
-      if (g.env_dbg)
+      const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2, a.n_cu);
+      if (a.env_dbg)
         hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                           EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc,
-                           g.env_dbg);
+                           EV2_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc,
+                           a.env_dbg);
       else
         hipLaunchKernelGGL(k_env_windows2<false>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                           EV2_LDS_BYTES, stream, d_pcm, d_songs, d_stats, g.tb, d_energies, d_lc, 0);
+                           EV2_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc, 0);
     }
     hipStream_t ts = stream;
-    if ((what & 3) && g.side_ok) { /* something to overlap with */
-      BL_HIP_CHECK(hipEventRecord(g.ev_env, stream));
-      BL_HIP_CHECK(hipStreamWaitEvent(g.side, g.ev_env, 0));
-      ts = g.side;
+    if ((what & 3) && a.side) { /* something to overlap with */
+      BL_HIP_CHECK(hipEventRecord(a.ev_env, stream));
+      BL_HIP_CHECK(hipStreamWaitEvent(a.side, a.ev_env, 0));
+      ts = a.side;
       tail_async = true;
     }
     {
-      ProfScope ps(PK_TAIL, ts);
-      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(128), 0, ts, d_songs, d_lc, n_songs, d_results,
+      Mark m(a.mark, a.mark_user, PK_TAIL, ts);
+      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(128), 0, ts, a.songs, a.lc, n_songs, a.results,
                          what);
     }
-    if (tail_async) BL_HIP_CHECK(hipEventRecord(g.ev_tail, g.side));
+    if (tail_async) BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
   }
   /* The short amplitude kernel goes before the wide frequency pass: the tail's 54 KB
    * workgroups only reach a CU when the dispatcher has no pending frequency workgroup to put
    * there, so they have to be resident before that pass begins (launched after it, the tail
    * started ~60 ms late and ~10 ms of it were exposed per 8 192 songs). */
   if (what & 1) {
-    ProfScope ps(PK_AMP, stream);
-    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, d_songs, d_stats, d_hist,
-                       d_results);
+    Mark m(a.mark, a.mark_user, PK_AMP, stream);
+    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, a.songs, a.stats, a.hist,
+                       a.results);
   }
   if (what & 2) {
     {
-      ProfScope ps(PK_FREQ, stream);
-      hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream, d_pcm,
-                         d_songs, g.tb, d_partial);
+      Mark m(a.mark, a.mark_user, PK_FREQ, stream);
+      hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream, a.pcm,
+                         a.songs, a.tb, a.spectrum);
     }
-    ProfScope ps(PK_FREQ_FIN, stream);
-    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, d_partial, d_songs,
-                       d_results);
+    Mark m(a.mark, a.mark_user, PK_FREQ_FIN, stream);
+    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, a.spectrum, a.songs,
+                       a.results);
   }
-  if (tail_async) BL_HIP_CHECK(hipStreamWaitEvent(stream, g.ev_tail, 0));
-  if (what == 7) hipLaunchKernelGGL(k_force, dim3(tb64), dim3(64), 0, stream, d_results, n_songs);
+  if (tail_async) BL_HIP_CHECK(hipStreamWaitEvent(stream, a.ev_tail, 0));
+  if (what == 7) hipLaunchKernelGGL(k_force, dim3(tb64), dim3(64), 0, stream, a.results, n_songs);
   BL_HIP_CHECK(hipGetLastError());
-  BL_HIP_CHECK(hipEventRecord(g.ev_ws, stream));
-  g.ws_used = true;
   return BL_OK;
 }
 
-int analyze_device(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
-                   bl_amd_song_result *d_results, hipStream_t stream, int what) {
-  const int GROUP = 32768;
-  for (int b = 0; b < n_songs; b += GROUP) {
-    const int cnt = n_songs - b < GROUP ? n_songs - b : GROUP;
-    if (b) BL_HIP_CHECK(hipStreamSynchronize(stream)); /* workspace is reused */
-    if (analyze_group(d_pcm, h_desc + b, cnt, d_results + b, stream, what) != BL_OK)
-      return BL_UNEXPECTED;
-  }
+int blk_synth(hipStream_t s, int16_t *pcm, const bl_dsong *d_songs, int n_songs, int max_n,
+              int n_cu, unsigned seed_base, unsigned rate) {
+  const int gx = grid_x_for(((long long)max_n + 255) / 256, n_songs, 8, n_cu);
+  hipLaunchKernelGGL(k_synth, dim3(gx, n_songs), dim3(256), 0, s, pcm, d_songs, seed_base, rate);
+  BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }
 
-} // namespace
-
-/* ========================================================================= */
-/* C-ABI                                                                      */
-
-extern "C" {
-
-int bl_amd_device_count(void) {
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
-  return count;
-}
-
-int bl_amd_init(int device) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  return init_locked(device);
-}
-
-int bld_ready(void) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (g.ready) {
-    if (hipSetDevice(g.device) != hipSuccess) return BL_UNEXPECTED;
-    return BL_OK;
-  }
-  return init_locked(0);
-}
-
-void bl_amd_profile(int enable) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  g.prof = enable != 0;
-}
-
-void bl_amd_profile_reset(void) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  prof_collect();
-  for (int k = 0; k < PK_COUNT; ++k) { g.prof_ms[k] = 0; g.prof_n[k] = 0; }
-}
-
-double bl_amd_profile_ms(const char *name, int *launches) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  prof_collect();
-  for (int k = 0; k < PK_COUNT; ++k)
-    if (!strcmp(name, kProfNames[k])) {
-      if (launches) *launches = g.prof_n[k];
-      return g.prof_ms[k];
-    }
-  if (launches) *launches = 0;
-  return -1.0;
-}
-
-int bl_amd_analyze_batch_device(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
-                                bl_amd_song_result *d_results, void *stream) {
-  if (n_songs <= 0 || !d_pcm || !h_desc || !d_results) return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  return analyze_device(d_pcm, h_desc, n_songs, d_results, static_cast<hipStream_t>(stream), 7);
-}
-
-int bl_amd_synth_pcm_device(int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
-                            uint32_t seed_base, uint32_t sample_rate, void *stream) {
-  if (n_songs <= 0 || !d_pcm || !h_desc) return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int GROUP = 32768;
-  for (int b = 0; b < n_songs; b += GROUP) {
-    const int cnt = n_songs - b < GROUP ? n_songs - b : GROUP;
-    std::vector<bl_dsong> hs;
-    long long env_total;
-    int max_n;
-    if (fill_songs(h_desc + b, cnt, hs, env_total, max_n) != BL_OK) return BL_UNEXPECTED;
-    if (b) BL_HIP_CHECK(hipStreamSynchronize(s));
-    if (ensure(g.songs, sizeof(bl_dsong) * cnt) != BL_OK) return BL_UNEXPECTED;
-    BL_HIP_CHECK(hipMemcpyAsync(g.songs.p, hs.data(), sizeof(bl_dsong) * cnt, hipMemcpyHostToDevice, s));
-    BL_HIP_CHECK(hipStreamSynchronize(s));
-    const int gx = grid_x_for(((long long)max_n + 255) / 256, cnt, 8);
-    hipLaunchKernelGGL(k_synth, dim3(gx, cnt), dim3(256), 0, s, d_pcm,
-                       static_cast<const bl_dsong *>(g.songs.p), seed_base + (uint32_t)b, sample_rate);
-    BL_HIP_CHECK(hipGetLastError());
-  }
-  return BL_OK;
-}
-
-static int matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin, int n_rows,
-                         float *d_out, void *stream, bool cosine) {
-  if (n <= 0 || n_rows <= 0 || row_begin < 0 || row_begin + n_rows > n || !d_vecs || !d_out)
-    return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int row_begin,
+                 int n_rows, float *d_out, bool cosine, blk_mark_fn mark, void *mark_user) {
   const float4 *v = reinterpret_cast<const float4 *>(d_vecs);
   const int gx = (n + 1023) / 1024;
   const int chunk = 65535 * BL_PW_ROWS; /* rows per launch (gridDim.y limit) */
   for (int r0 = 0; r0 < n_rows; r0 += chunk) {
     const int cnt = n_rows - r0 < chunk ? n_rows - r0 : chunk;
     const int gy = (cnt + BL_PW_ROWS - 1) / BL_PW_ROWS;
-    ProfScope ps(PK_DIST, s);
+    Mark m(mark, mark_user, PK_DIST, s);
     if (cosine)
       hipLaunchKernelGGL(k_pairwise<true>, dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
@@ -1568,23 +1284,8 @@ static int matrix_device(const struct force_vector_s *d_vecs, int n, int row_beg
   return BL_OK;
 }
 
-int bl_amd_distance_matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin,
-                                  int n_rows, float *d_out, void *stream) {
-  return matrix_device(d_vecs, n, row_begin, n_rows, d_out, stream, false);
-}
-
-int bl_amd_cosine_matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin,
-                                int n_rows, float *d_out, void *stream) {
-  return matrix_device(d_vecs, n, row_begin, n_rows, d_out, stream, true);
-}
-
-int bl_amd_playlist_device(const struct force_vector_s *d_vecs, int n, int seed_index,
-                           int32_t *d_order, float *d_dist, void *stream) {
-  if (n <= 0 || seed_index < 0 || seed_index >= n || !d_vecs || !d_order || !d_dist)
-    return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+int blk_playlist(hipStream_t s, const struct force_vector_s *d_vecs, int n, int seed_index,
+                 int32_t *d_order, float *d_dist) {
   const int gx = (n + 255) / 256;
   hipLaunchKernelGGL(k_seed_dist, dim3(gx), dim3(256), 0, s, reinterpret_cast<const float4 *>(d_vecs),
                      n, seed_index, d_dist);
@@ -1593,268 +1294,53 @@ int bl_amd_playlist_device(const struct force_vector_s *d_vecs, int n, int seed_
   return BL_OK;
 }
 
-int bl_amd_playlist_host(const struct force_vector_s *h_vecs, int n, int seed_index,
-                         int32_t *h_order, float *h_dist) {
-  if (n <= 0 || !h_vecs || !h_order) return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  void *dv = nullptr, *dord = nullptr, *dd = nullptr;
-  int rc = BL_UNEXPECTED;
-  if (hipMalloc(&dv, sizeof(struct force_vector_s) * (size_t)n) == hipSuccess &&
-      hipMalloc(&dord, sizeof(int32_t) * (size_t)n) == hipSuccess &&
-      hipMalloc(&dd, sizeof(float) * (size_t)n) == hipSuccess &&
-      hipMemcpy(dv, h_vecs, sizeof(struct force_vector_s) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
-      bl_amd_playlist_device(static_cast<struct force_vector_s *>(dv), n, seed_index,
-                             static_cast<int32_t *>(dord), static_cast<float *>(dd), nullptr) == BL_OK &&
-      hipMemcpy(h_order, dord, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess &&
-      (!h_dist || hipMemcpy(h_dist, dd, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess))
-    rc = BL_OK;
-  if (dv) (void)hipFree(dv);
-  if (dord) (void)hipFree(dord);
-  if (dd) (void)hipFree(dd);
-  return rc;
-}
-
-static int matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out, bool cosine) {
-  if (n <= 0 || !h_vecs || !h_out) return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  void *dv = nullptr, *dout = nullptr;
-  BL_HIP_CHECK(hipMalloc(&dv, sizeof(struct force_vector_s) * (size_t)n));
-  if (hipMalloc(&dout, sizeof(float) * (size_t)n * n) != hipSuccess) { (void)hipFree(dv); return BL_UNEXPECTED; }
-  int rc = BL_UNEXPECTED;
-  if (hipMemcpy(dv, h_vecs, sizeof(struct force_vector_s) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
-      matrix_device(static_cast<struct force_vector_s *>(dv), n, 0, n, static_cast<float *>(dout),
-                    nullptr, cosine) == BL_OK &&
-      hipMemcpy(h_out, dout, sizeof(float) * (size_t)n * n, hipMemcpyDeviceToHost) == hipSuccess)
-    rc = BL_OK;
-  (void)hipFree(dv);
-  (void)hipFree(dout);
-  return rc;
-}
-
-int bl_amd_distance_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out) {
-  return matrix_host(h_vecs, n, h_out, false);
-}
-int bl_amd_cosine_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out) {
-  return matrix_host(h_vecs, n, h_out, true);
-}
-
-/* ---- host-memory batch: pinned staging, copy/compute overlap on 2 streams ---- */
-#ifndef BL_STAGE_THREADS
-#define BL_STAGE_THREADS 8 /* host threads of the staging copy */
-#endif
-int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samples,
-                              const int32_t *channels, const uint64_t *duration, int n_songs,
-                              bl_amd_song_result *h_results) {
-  if (n_songs <= 0 || !h_pcm || !n_samples || !channels || !duration || !h_results)
-    return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  for (int k = 0; k < 2; ++k)
-    if (!g.streams[k]) BL_HIP_CHECK(hipStreamCreateWithFlags(&g.streams[k], hipStreamNonBlocking));
-  if (ensure(g.results, sizeof(bl_amd_song_result) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
-  bl_amd_song_result *d_res = static_cast<bl_amd_song_result *>(g.results.p);
-
-  /* waves of songs of at most WAVE_BYTES of PCM each (one song may exceed it): large enough
-   * that the ~20 ms latency of the serial envelope tail (paid once per wave) stays below
-   * the wave's transfer time, small enough for two pinned and two device buffers */
-  const size_t WAVE_BYTES = (size_t)2 << 30;
-  int begin = 0, wave = 0;
-  int rc = BL_OK;
-  /* the shared scratch (stats, histograms, ...) is per launch group, so waves
-   * are serialised on the compute side by an event chain; copies still overlap */
-  hipEvent_t done[2] = {nullptr, nullptr};
-  for (int k = 0; k < 2; ++k) BL_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
-  bool used[2] = {false, false};
-  while (begin < n_songs && rc == BL_OK) {
-    const int k = wave & 1;
-    size_t elems = 0;
-    int end = begin;
-    std::vector<bl_amd_song_desc> desc;
-    while (end < n_songs) {
-      const size_t need = ((size_t)n_samples[end] + 7) & ~(size_t)7;
-      if (end > begin && (elems + need) * 2 > WAVE_BYTES) break;
-      bl_amd_song_desc d;
-      d.pcm_offset = elems; d.n_samples = n_samples[end]; d.channels = channels[end];
-      d.duration = duration[end];
-      desc.push_back(d);
-      elems += need;
-      ++end;
-    }
-    const size_t bytes = elems * 2 + 64;
-    if (used[k]) { /* buffer k is free again once wave-2 has finished */
-      if (hipEventSynchronize(done[k]) != hipSuccess) { rc = BL_UNEXPECTED; break; }
-    }
-    if (g.pinned_cap[k] < bytes) {
-      if (g.pinned[k]) (void)hipHostFree(g.pinned[k]);
-      g.pinned[k] = nullptr; g.pinned_cap[k] = 0;
-      if (hipHostMalloc(&g.pinned[k], bytes, hipHostMallocDefault) != hipSuccess) { rc = BL_UNEXPECTED; break; }
-      g.pinned_cap[k] = bytes;
-    }
-    if (ensure(g.arena[k], bytes) != BL_OK) { rc = BL_UNEXPECTED; break; }
-    int16_t *stage = static_cast<int16_t *>(g.pinned[k]);
-    {
-      /* staging copy on several host threads: one thread moves ~10 GB/s, the link takes 50+ */
-      const int n_thr = (int)std::min<size_t>(BL_STAGE_THREADS, std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
-      auto copy_range = [&](int t) {
-        for (size_t i = (size_t)t; i < desc.size(); i += (size_t)n_thr) {
-          memcpy(stage + desc[i].pcm_offset, h_pcm[begin + i], (size_t)desc[i].n_samples * 2);
-          const size_t padded = ((size_t)desc[i].n_samples + 7) & ~(size_t)7;
-          for (size_t z = desc[i].n_samples; z < padded; ++z) stage[desc[i].pcm_offset + z] = 0;
-        }
-      };
-      std::vector<std::thread> pool;
-      for (int t = 1; t < n_thr; ++t) pool.emplace_back(copy_range, t);
-      copy_range(0);
-      for (auto &th : pool) th.join();
-    }
-    hipStream_t s = g.streams[k];
-    if (hipMemcpyAsync(g.arena[k].p, stage, elems * 2, hipMemcpyHostToDevice, s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
-    /* compute of this wave waits for the previous wave's compute (shared scratch) */
-    if (used[k ^ 1] && hipStreamWaitEvent(s, done[k ^ 1], 0) != hipSuccess) { rc = BL_UNEXPECTED; break; }
-    if (analyze_device(static_cast<const int16_t *>(g.arena[k].p), desc.data(), (int)desc.size(),
-                       d_res + begin, s, 7) != BL_OK) { rc = BL_UNEXPECTED; break; }
-    if (hipEventRecord(done[k], s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
-    used[k] = true;
-    begin = end;
-    ++wave;
-  }
-  for (int k = 0; k < 2; ++k) {
-    if (g.streams[k] && hipStreamSynchronize(g.streams[k]) != hipSuccess) rc = BL_UNEXPECTED;
-    (void)hipEventDestroy(done[k]);
-  }
-  if (rc == BL_OK &&
-      hipMemcpy(h_results, d_res, sizeof(bl_amd_song_result) * (size_t)n_songs, hipMemcpyDeviceToHost) != hipSuccess)
-    rc = BL_UNEXPECTED;
-  return rc;
-}
-
-/* ---- helpers behind the reference-API shims of bl_api.c ---- */
-int bld_analyze_one_host(const int16_t *h_pcm, int n, int channels, uint64_t duration, int what,
-                         bl_amd_song_result *res) {
-  if (!h_pcm || !res) return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  const size_t elems = ((size_t)n + 7) & ~(size_t)7;
-  if (ensure(g.arena[0], elems * 2 + 64) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.results, sizeof(bl_amd_song_result)) != BL_OK) return BL_UNEXPECTED;
-  BL_HIP_CHECK(hipMemsetAsync(g.arena[0].p, 0, elems * 2, nullptr));
-  BL_HIP_CHECK(hipMemcpy(g.arena[0].p, h_pcm, (size_t)n * 2, hipMemcpyHostToDevice));
-  BL_HIP_CHECK(hipMemsetAsync(g.results.p, 0, sizeof(bl_amd_song_result), nullptr));
-  bl_amd_song_desc d;
-  d.pcm_offset = 0; d.n_samples = n; d.channels = channels; d.duration = duration ? duration : 1;
-  if (analyze_device(static_cast<const int16_t *>(g.arena[0].p), &d, 1,
-                     static_cast<bl_amd_song_result *>(g.results.p), nullptr, what) != BL_OK)
-    return BL_UNEXPECTED;
-  BL_HIP_CHECK(hipMemcpy(res, g.results.p, sizeof(bl_amd_song_result), hipMemcpyDeviceToHost));
+int blk_narrow_s32(hipStream_t s, const int32_t *d_in, int16_t *d_out, size_t n, int n_cu) {
+  /* the vector body needs a 16-byte aligned input and an 8-byte aligned output; anything
+   * else (and the last n % 4 elements) goes element by element */
+  const bool aligned = ((reinterpret_cast<size_t>(d_in) & 15) == 0) && ((reinterpret_cast<size_t>(d_out) & 7) == 0);
+  const size_t nvec = aligned ? n / 4 : 0;
+  const size_t work = aligned ? nvec : n;
+  size_t blocks = (work + 255) / 256;
+  const size_t cap = (size_t)n_cu * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_narrow_s32, dim3((unsigned)blocks), dim3(256), 0, s,
+                     reinterpret_cast<const int4 *>(d_in), reinterpret_cast<uint2 *>(d_out), nvec, d_in,
+                     d_out, n);
+  BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }
 
-int bld_mean_variance_host(const int16_t *h_pcm, int n, int have_mean, int mean_in, int *mean_out,
-                           int *variance_out) {
-  if (!h_pcm || n <= 0) return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  const size_t elems = ((size_t)n + 7) & ~(size_t)7;
-  if (ensure(g.arena[0], elems * 2 + 64) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.songs, sizeof(bl_dsong)) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.stats, sizeof(bl_dstats)) != BL_OK) return BL_UNEXPECTED;
-  if (ensure(g.hist, sizeof(unsigned) * BL_HIST_BINS) != BL_OK) return BL_UNEXPECTED;
-  BL_HIP_CHECK(hipMemcpy(g.arena[0].p, h_pcm, (size_t)n * 2, hipMemcpyHostToDevice));
-  bl_dsong s;
-  memset(&s, 0, sizeof s);
-  s.n = n; s.channels = 1; s.duration = 1;
-  BL_HIP_CHECK(hipMemcpy(g.songs.p, &s, sizeof s, hipMemcpyHostToDevice));
-  BL_HIP_CHECK(hipMemsetAsync(g.hist.p, 0, sizeof(unsigned) * BL_HIST_BINS, nullptr));
-  bl_dstats *d_stats = static_cast<bl_dstats *>(g.stats.p);
-  const bl_dsong *d_songs = static_cast<const bl_dsong *>(g.songs.p);
-  const int gx = grid_x_for(((long long)n / 8 + 255) / 256, 1, 8);
-  hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(64), 0, nullptr, d_stats, 1);
-  hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx, 1), dim3(256), 0, nullptr,
-                     static_cast<const int16_t *>(g.arena[0].p), d_songs, d_stats,
-                     static_cast<unsigned *>(g.hist.p));
-  bl_dstats st;
-  BL_HIP_CHECK(hipMemcpy(&st, d_stats, sizeof st, hipMemcpyDeviceToHost));
-  /* ref helpers.c:30-37 */
-  const int mean = have_mean ? mean_in : (int)(unsigned)(st.sum & 0xFFFFFFFFull) / n;
-  if (mean_out) *mean_out = mean;
-  if (variance_out) {
-    /* always the exact wrapping form (ref helpers.c:39-49) for the stand-alone helper */
-    st.mean = mean; st.wrap_pass = 1; st.wrap_acc = 0;
-    BL_HIP_CHECK(hipMemcpy(d_stats, &st, sizeof st, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_variance_wrap, dim3(gx, 1), dim3(256), 0, nullptr,
-                       static_cast<const int16_t *>(g.arena[0].p), d_songs, d_stats);
-    BL_HIP_CHECK(hipMemcpy(&st, d_stats, sizeof st, hipMemcpyDeviceToHost));
-    *variance_out = (int)(st.wrap_acc / n);
-  }
+int blk_scatter_vecs(hipStream_t s, const struct force_vector_s *d_in, const int32_t *d_order,
+                     struct force_vector_s *d_out, int n) {
+  hipLaunchKernelGGL(k_scatter_vecs, dim3((n + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<const float4 *>(d_in), d_order, reinterpret_cast<float4 *>(d_out), n);
+  BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }
 
-int bld_rect_filter_host(double *h_out, const double *h_in, int n, int width) {
-  if (!h_out || !h_in || n <= 0 || width <= 0 || width > n) return BL_UNEXPECTED;
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (ensure(g.misc, sizeof(double) * 2 * (size_t)n) != BL_OK) return BL_UNEXPECTED;
-  double *d_out = static_cast<double *>(g.misc.p), *d_in = d_out + n;
-  BL_HIP_CHECK(hipMemcpy(d_out, h_out, sizeof(double) * n, hipMemcpyHostToDevice));
-  BL_HIP_CHECK(hipMemcpy(d_in, h_in, sizeof(double) * n, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_rect_filter, dim3(1), dim3(1), 0, nullptr, d_out, d_in, n, width);
-  BL_HIP_CHECK(hipMemcpy(h_out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+int blk_extract_vecs(hipStream_t s, const bl_amd_song_result *d_res, struct force_vector_s *d_out,
+                     int n) {
+  hipLaunchKernelGGL(k_extract_vecs, dim3((n + 255) / 256), dim3(256), 0, s, d_res,
+                     reinterpret_cast<float4 *>(d_out), n);
+  BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }
 
-int bld_pair_host(const struct force_vector_s *a, const struct force_vector_s *b, int cosine,
-                  float *out) {
-  if (bld_ready() != BL_OK) return BL_UNEXPECTED;
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (ensure(g.misc, 64) != BL_OK) return BL_UNEXPECTED;
-  const float4 va = make_float4(a->tempo, a->amplitude, a->frequency, a->attack);
-  const float4 vb = make_float4(b->tempo, b->amplitude, b->frequency, b->attack);
-  hipLaunchKernelGGL(k_pair, dim3(1), dim3(1), 0, nullptr, va, vb, cosine,
-                     static_cast<float *>(g.misc.p));
-  BL_HIP_CHECK(hipMemcpy(out, g.misc.p, sizeof(float), hipMemcpyDeviceToHost));
+int blk_scan_one(hipStream_t s, const int16_t *pcm, const bl_dsong *d_songs, bl_dstats *d_stats,
+                 unsigned *d_hist, int n, int n_cu) {
+  const int gx = grid_x_for(((long long)n / 8 + 255) / 256, 1, 8, n_cu);
+  BL_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * BL_HIST_BINS, s));
+  hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(64), 0, s, d_stats, 1);
+  hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx, 1), dim3(256), 0, s, pcm, d_songs, d_stats, d_hist);
+  BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }
 
-/* diagnostic: the per-window energies (ref tempo_atk_sort.c:150, filtered_array) of the
- * most recent batch, songs concatenated, nb_frames slots per song (last two are unused) */
-long long bl_amd_last_energies(float *h_out, long long max_elems) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.ready || !g.energies.p || g.last_env_total <= 0) return 0;
-  const long long n = g.last_env_total < max_elems ? g.last_env_total : max_elems;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpy(h_out, g.energies.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
-    return -1;
-  return n;
+int blk_variance_wrap_one(hipStream_t s, const int16_t *pcm, const bl_dsong *d_songs,
+                          bl_dstats *d_stats, int n, int n_cu) {
+  const int gx = grid_x_for(((long long)n / 8 + 255) / 256, 1, 8, n_cu);
+  hipLaunchKernelGGL(k_variance_wrap, dim3(gx, 1), dim3(256), 0, s, pcm, d_songs, d_stats);
+  BL_HIP_CHECK(hipGetLastError());
+  return BL_OK;
 }
-
-void bl_amd_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.ready) return;
-  (void)hipDeviceSynchronize();
-  prof_collect();
-  Buf *bufs[] = {&g.songs, &g.stats, &g.hist, &g.partial, &g.energies, &g.lc, &g.results, &g.misc,
-                 &g.arena[0], &g.arena[1]};
-  for (Buf *b : bufs) {
-    if (b->p) (void)hipFree(b->p);
-    b->p = nullptr; b->cap = 0;
-  }
-  for (int k = 0; k < 2; ++k) {
-    if (g.pinned[k]) (void)hipHostFree(g.pinned[k]);
-    g.pinned[k] = nullptr; g.pinned_cap[k] = 0;
-    if (g.streams[k]) (void)hipStreamDestroy(g.streams[k]);
-    g.streams[k] = nullptr;
-  }
-  if (g.tables_mem) (void)hipFree(g.tables_mem);
-  g.tables_mem = nullptr;
-  if (g.side_ok) {
-    (void)hipStreamDestroy(g.side);
-    (void)hipEventDestroy(g.ev_env);
-    (void)hipEventDestroy(g.ev_tail);
-    (void)hipEventDestroy(g.ev_ws);
-    g.ws_used = false;
-    g.side_ok = false;
-  }
-  g.ready = false;
-}
-
-} /* extern "C" */

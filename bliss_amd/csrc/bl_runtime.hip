@@ -1,0 +1,843 @@
+/*
+ * bl_runtime.hip — contexts, workspaces, streams and the single-device C-ABI of
+ * include/bliss_amd.h.  Host code only (compiled by hipcc for the HIP runtime API); every
+ * kernel lives in bl_kernels.hip and is reached through the launchers of bl_launch.h.
+ *
+ * Contexts.  A bl_amd_ctx owns one device's scratch workspace, internal streams and pinned
+ * staging.  The plain entry points (bl_amd_analyze_batch_device, ...) use the calling
+ * thread's default context: the device chosen with bl_amd_init() on that thread, else the
+ * process default (the first bl_amd_init of the process, else device 0).  One process can
+ * therefore drive several GPUs from several threads, and explicit contexts
+ * (bl_amd_ctx_create) give independent workspaces on one device.
+ *
+ * Asynchrony.  bl_amd_analyze_batch_device() only enqueues: descriptors go through a ring of
+ * pinned slots (hipMemcpyAsync from pinned memory does not block), launch groups of more than
+ * 32 768 songs follow each other on the stream, and the shared workspace is handed from one
+ * batch to the next by an event, not by a host synchronisation.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "bl_runtime.h"
+
+namespace {
+
+std::mutex g_mu;                       /* guards the default-context table */
+bl_amd_ctx *g_default[BL_MAX_DEVICES]; /* lazily created, one per device */
+std::atomic<int> g_process_device{-1};
+thread_local int tl_device = -1;
+std::atomic<int> g_host_mode{-1}; /* -1: from BL_AMD_HOST_MODE or staged */
+
+/* makes the context's device current for the duration of a call and puts the caller's back:
+ * the current device is per-thread state shared with whoever else uses HIP in this thread
+ * (torch, the caller's own code) */
+struct DevGuard {
+  int prev = -1;
+  bool changed = false;
+  bool ok = true;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    if (prev != dev) {
+      ok = hipSetDevice(dev) == hipSuccess;
+      changed = ok && prev >= 0;
+    }
+  }
+  ~DevGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+void release_buf(bl_buf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+int ctx_init(bl_amd_ctx *c, int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    fprintf(stderr, "bliss_amd: no HIP device available (%s); this library has no CPU path\n",
+            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return BL_UNEXPECTED;
+  }
+  if (device < 0 || device >= count || device >= BL_MAX_DEVICES) {
+    fprintf(stderr, "bliss_amd: device %d out of range (%d visible)\n", device, count);
+    return BL_UNEXPECTED;
+  }
+  DevGuard dg(device);
+  if (!dg.ok) return BL_UNEXPECTED;
+  hipDeviceProp_t prop;
+  BL_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  std::vector<unsigned char> h(blk_tables_bytes());
+  blk_tables_fill_host(h.data());
+  BL_HIP_CHECK(hipMalloc(&c->tables_mem, h.size()));
+  BL_HIP_CHECK(hipMemcpy(c->tables_mem, h.data(), h.size(), hipMemcpyHostToDevice));
+  c->tb = blk_tables_bind(c->tables_mem);
+  if (blk_configure_device() != BL_OK) return BL_UNEXPECTED;
+  {
+    const char *d = getenv("BL_AMD_ENV_DBG"); /* bit 0: skip the ordered sums, bit 1: skip compute */
+    c->env_dbg = d ? atoi(d) : 0;
+    /* songs per launch group; lowered by the tests to exercise the multi-group path */
+    const char *gs = getenv("BL_AMD_GROUP_SONGS");
+    int g = gs ? atoi(gs) : BL_GROUP_SONGS_MAX;
+    c->group_songs = g < 1 ? 1 : (g > BL_GROUP_SONGS_MAX ? BL_GROUP_SONGS_MAX : g);
+  }
+  BL_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_env, hipEventDisableTiming));
+  BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+  BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_ws, hipEventDisableTiming));
+  for (int k = 0; k < BL_PIN_SLOTS; ++k)
+    BL_HIP_CHECK(hipEventCreateWithFlags(&c->ring[k].ev, hipEventDisableTiming));
+  return BL_OK;
+}
+
+void prof_collect(bl_amd_ctx *c) {
+  for (auto &e : c->events) {
+    float ms = 0;
+    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      c->prof_ms[e.k] += ms;
+      c->prof_n[e.k] += 1;
+    }
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  c->events.clear();
+}
+
+void unregister_wave(bl_amd_ctx *c, int k) {
+  for (void *p : c->registered[k]) (void)hipHostUnregister(p);
+  c->registered[k].clear();
+}
+
+void ctx_release(bl_amd_ctx *c) {
+  DevGuard dg(c->device);
+  if (!dg.ok) return;
+  (void)hipDeviceSynchronize();
+  prof_collect(c);
+  bl_buf *bufs[] = {&c->songs,   &c->stats,   &c->hist, &c->spectrum, &c->energies, &c->lc,
+                    &c->results, &c->misc,    &c->arena[0], &c->arena[1]};
+  for (bl_buf *b : bufs) release_buf(*b);
+  for (int k = 0; k < 2; ++k) {
+    unregister_wave(c, k);
+    if (c->pinned[k]) (void)hipHostFree(c->pinned[k]);
+    c->pinned[k] = nullptr;
+    c->pinned_cap[k] = 0;
+    if (c->streams[k]) (void)hipStreamDestroy(c->streams[k]);
+    c->streams[k] = nullptr;
+  }
+  for (int k = 0; k < BL_PIN_SLOTS; ++k) {
+    if (c->ring[k].p) (void)hipHostFree(c->ring[k].p);
+    if (c->ring[k].ev) (void)hipEventDestroy(c->ring[k].ev);
+    c->ring[k] = bl_pin_slot();
+  }
+  if (c->tables_mem) (void)hipFree(c->tables_mem);
+  c->tables_mem = nullptr;
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_env) (void)hipEventDestroy(c->ev_env);
+  if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+  if (c->ev_ws) (void)hipEventDestroy(c->ev_ws);
+  c->side = nullptr;
+  c->ev_env = c->ev_tail = c->ev_ws = nullptr;
+  c->ws_used = false;
+}
+
+int current_device(void) {
+  if (tl_device >= 0) return tl_device;
+  const int d = g_process_device.load();
+  return d >= 0 ? d : 0;
+}
+
+void mark_cb(void *user, int k, hipStream_t s, int begin) {
+  bl_amd_ctx *c = static_cast<bl_amd_ctx *>(user);
+  if (!c->prof) return;
+  if (begin) {
+    bl_amd_ctx::Ev e{k, nullptr, nullptr};
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+    (void)hipEventRecord(e.a, s);
+    c->open.push_back(e);
+  } else {
+    for (size_t i = c->open.size(); i-- > 0;)
+      if (c->open[i].k == k) {
+        (void)hipEventRecord(c->open[i].b, s);
+        c->events.push_back(c->open[i]);
+        c->open.erase(c->open.begin() + (long)i);
+        break;
+      }
+  }
+}
+
+/* pinned slot of at least `bytes`; blocks only when BL_PIN_SLOTS batches are still in flight */
+int ring_get(bl_amd_ctx *c, size_t bytes, bl_pin_slot **out) {
+  bl_pin_slot &s = c->ring[c->ring_next];
+  c->ring_next = (c->ring_next + 1) % BL_PIN_SLOTS;
+  if (s.busy) {
+    BL_HIP_CHECK(hipEventSynchronize(s.ev));
+    s.busy = false;
+  }
+  if (s.cap < bytes) {
+    if (s.p) (void)hipHostFree(s.p);
+    s.p = nullptr;
+    s.cap = 0;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    BL_HIP_CHECK(hipHostMalloc(&s.p, cap, hipHostMallocDefault));
+    s.cap = cap;
+  }
+  *out = &s;
+  return BL_OK;
+}
+
+int validate_desc(const bl_amd_song_desc &d, int i) {
+  if (d.n_samples < 5120 || (d.channels != 1 && d.channels != 2) || d.duration == 0 ||
+      (d.pcm_offset & 7)) {
+    fprintf(stderr,
+            "bliss_amd: song %d rejected (n_samples=%d channels=%d duration=%llu offset=%llu): "
+            "need n_samples >= 5120, channels 1|2, duration > 0, offset %% 8 == 0\n",
+            i, d.n_samples, d.channels, (unsigned long long)d.duration,
+            (unsigned long long)d.pcm_offset);
+    return BL_UNEXPECTED;
+  }
+  return BL_OK;
+}
+
+/* host mirror of the per-song geometry (integer work of ref tempo_atk_sort.c:63-67,
+ * frequency_sort.c:50) for one launch group, written to `out` (pinned) */
+void fill_group(const bl_amd_song_desc *desc, int n_songs, bl_dsong *out, long long &env_total,
+                int &max_n) {
+  env_total = 0;
+  max_n = 0;
+  for (int i = 0; i < n_songs; ++i) {
+    const bl_amd_song_desc &d = desc[i];
+    bl_dsong &s = out[i];
+    s.pcm_off = d.pcm_offset;
+    s.duration = d.duration;
+    s.n = d.n_samples;
+    s.channels = d.channels;
+    s.n_frames = (d.n_samples / d.channels) / 512;
+    s.nb_frames = (d.n_samples - (d.n_samples % 512)) * 2 / 512;
+    s.n_windows = s.nb_frames - 2;
+    s.env_off = env_total;
+    s.reserved0 = 0;
+    s.out_idx = i;
+    s.reserved1 = 0;
+    env_total += s.nb_frames;
+    if (d.n_samples > max_n) max_n = d.n_samples;
+  }
+  /* Mixed-length corpora: process the records longest first.  The 64 songs that share a
+   * wave of k_env_tail then have similar lengths (its straight-line steady-state path is
+   * wave-uniform), and the long songs do not straggle at the end of the per-song grids.
+   * Results go back to the caller's order through out_idx; scratch offsets keep the
+   * caller's order too.  Equal lengths: the order is left alone. */
+  bool mixed = false;
+  for (int i = 1; i < n_songs && !mixed; ++i) mixed = out[i].n != out[0].n;
+  if (mixed)
+    std::stable_sort(out, out + n_songs, [](const bl_dsong &a, const bl_dsong &b) { return a.n > b.n; });
+}
+
+} // namespace
+
+int blr_ensure(bl_buf &b, size_t bytes) {
+  if (bytes <= b.cap) return BL_OK;
+  if (b.p) {
+    /* growth is rare (capacity is kept); work in flight may still use the old block */
+    BL_HIP_CHECK(hipDeviceSynchronize());
+    BL_HIP_CHECK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t cap = bytes + bytes / 8 + 4096;
+  BL_HIP_CHECK(hipMalloc(&b.p, cap));
+  b.cap = cap;
+  return BL_OK;
+}
+
+bl_amd_ctx *blr_default_ctx(void) {
+  const int dev = current_device();
+  if (dev < 0 || dev >= BL_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_default[dev]) {
+    bl_amd_ctx *c = new bl_amd_ctx();
+    if (ctx_init(c, dev) != BL_OK) {
+      ctx_release(c);
+      delete c;
+      return nullptr;
+    }
+    g_default[dev] = c;
+  }
+  return g_default[dev];
+}
+
+/* Enqueue the analysis of n_songs device-resident songs on `stream` (caller holds c->mu and
+ * has made c->device current).  Nothing here waits for the device. */
+int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
+                       bl_amd_song_result *d_results, hipStream_t stream, int what) {
+  for (int i = 0; i < n_songs; ++i)
+    if (validate_desc(h_desc[i], i) != BL_OK) return BL_UNEXPECTED;
+  const int G = c->group_songs;
+  const int n_groups = (n_songs + G - 1) / G;
+  /* all descriptors of the call in one pinned slot, one asynchronous copy */
+  bl_pin_slot *slot = nullptr;
+  if (ring_get(c, sizeof(bl_dsong) * (size_t)n_songs, &slot) != BL_OK) return BL_UNEXPECTED;
+  bl_dsong *hs = static_cast<bl_dsong *>(slot->p);
+  std::vector<long long> env_total(n_groups);
+  std::vector<int> max_n(n_groups);
+  long long env_max = 0;
+  for (int gi = 0; gi < n_groups; ++gi) {
+    const int b = gi * G, cnt = std::min(G, n_songs - b);
+    fill_group(h_desc + b, cnt, hs + b, env_total[gi], max_n[gi]);
+    env_max = std::max(env_max, env_total[gi]);
+  }
+  const int gmax = std::min(G, n_songs);
+  /* the workspace is shared by every call on this context: a batch enqueued on another
+   * stream waits (on the device) for the previous user; the mutex only orders the enqueues */
+  if (c->ws_used) BL_HIP_CHECK(hipStreamWaitEvent(stream, c->ev_ws, 0));
+  if (blr_ensure(c->songs, sizeof(bl_dsong) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->stats, sizeof(bl_dstats) * (size_t)gmax) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->hist, sizeof(unsigned) * BL_HIST_BINS * (size_t)gmax) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->spectrum, sizeof(float) * 256 * (size_t)gmax) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->energies, sizeof(float) * (size_t)env_max) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->lc, sizeof(double) * (size_t)env_max) != BL_OK) return BL_UNEXPECTED;
+  bl_dsong *d_songs = static_cast<bl_dsong *>(c->songs.p);
+  BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs, sizeof(bl_dsong) * (size_t)n_songs, hipMemcpyHostToDevice,
+                              stream));
+  BL_HIP_CHECK(hipEventRecord(slot->ev, stream));
+  slot->busy = true;
+  for (int gi = 0; gi < n_groups; ++gi) {
+    const int b = gi * G, cnt = std::min(G, n_songs - b);
+    blk_analyze_args a;
+    a.pcm = d_pcm;
+    a.songs = d_songs + b;
+    a.stats = static_cast<bl_dstats *>(c->stats.p);
+    a.hist = static_cast<unsigned *>(c->hist.p);
+    a.spectrum = static_cast<float *>(c->spectrum.p);
+    a.energies = static_cast<float *>(c->energies.p);
+    a.lc = static_cast<double *>(c->lc.p);
+    a.results = d_results + b;
+    a.n_songs = cnt;
+    a.max_n = max_n[gi];
+    a.what = what;
+    a.n_cu = c->n_cu;
+    a.env_dbg = c->env_dbg;
+    a.tb = c->tb;
+    a.stream = stream;
+    a.side = c->side;
+    a.ev_env = c->ev_env;
+    a.ev_tail = c->ev_tail;
+    a.mark = c->prof ? mark_cb : nullptr;
+    a.mark_user = c;
+    if (blk_analyze(a) != BL_OK) return BL_UNEXPECTED;
+    c->last_env_total = env_total[gi];
+  }
+  BL_HIP_CHECK(hipEventRecord(c->ev_ws, stream));
+  c->ws_used = true;
+  return BL_OK;
+}
+
+/* ---- host-memory batch: pinned staging, copy/compute overlap on 2 streams ---- */
+#ifndef BL_STAGE_THREADS
+#define BL_STAGE_THREADS 8 /* host threads of the staging copy */
+#endif
+
+static int host_mode(void) {
+  int m = g_host_mode.load();
+  if (m < 0) {
+    const char *e = getenv("BL_AMD_HOST_MODE");
+    m = (e && !strcmp(e, "registered")) ? BL_AMD_HOST_REGISTERED : BL_AMD_HOST_STAGED;
+    g_host_mode.store(m);
+  }
+  return m;
+}
+
+int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, const int32_t *n_samples,
+                     const int32_t *channels, const uint64_t *duration, int n_songs,
+                     bl_amd_song_result *h_results, bl_amd_song_result **d_res_out) {
+  /* reject bad descriptors before anything is staged (a negative length would otherwise
+   * become a ~2^64-byte copy) */
+  for (int i = 0; i < n_songs; ++i) {
+    if (!h_pcm[i]) {
+      fprintf(stderr, "bliss_amd: song %d rejected: NULL sample pointer\n", i);
+      return BL_UNEXPECTED;
+    }
+    bl_amd_song_desc d;
+    d.pcm_offset = 0; d.n_samples = n_samples[i]; d.channels = channels[i]; d.duration = duration[i];
+    if (validate_desc(d, i) != BL_OK) return BL_UNEXPECTED;
+  }
+  for (int k = 0; k < 2; ++k)
+    if (!c->streams[k]) BL_HIP_CHECK(hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking));
+  if (blr_ensure(c->results, sizeof(bl_amd_song_result) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
+  bl_amd_song_result *d_res = static_cast<bl_amd_song_result *>(c->results.p);
+  const bool in_place = !pcm_is_s32 && host_mode() == BL_AMD_HOST_REGISTERED;
+
+  /* waves of songs of at most WAVE_BYTES of PCM each (one song may exceed it): large enough
+   * that the ~20 ms latency of the serial envelope tail (paid once per wave) stays below
+   * the wave's transfer time, small enough for two pinned and two device buffers */
+  const size_t WAVE_BYTES = (size_t)2 << 30;
+  int begin = 0, wave = 0;
+  int rc = BL_OK;
+  /* the scratch workspace is per context, so the waves' kernels follow each other (event
+   * chain inside blr_analyze_device); the copies of wave w+1 overlap the kernels of wave w */
+  hipEvent_t done[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; ++k) BL_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+  bool used[2] = {false, false};
+  while (begin < n_songs && rc == BL_OK) {
+    const int k = wave & 1;
+    size_t elems = 0;
+    int end = begin;
+    std::vector<bl_amd_song_desc> desc;
+    while (end < n_songs) {
+      const size_t need = ((size_t)n_samples[end] + 7) & ~(size_t)7;
+      if (end > begin && (elems + need) * 2 > WAVE_BYTES) break;
+      bl_amd_song_desc d;
+      d.pcm_offset = elems; d.n_samples = n_samples[end]; d.channels = channels[end];
+      d.duration = duration[end];
+      desc.push_back(d);
+      elems += need;
+      ++end;
+    }
+    const size_t bytes = elems * 2 + 64;
+    if (used[k]) { /* buffer k is free again once wave-2 has finished */
+      if (hipEventSynchronize(done[k]) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+      unregister_wave(c, k);
+    }
+    if (blr_ensure(c->arena[k], bytes) != BL_OK) { rc = BL_UNEXPECTED; break; }
+    hipStream_t s = c->streams[k];
+    int16_t *d_arena = static_cast<int16_t *>(c->arena[k].p);
+    if (in_place) {
+      /* pin the caller's buffers where they are (hipHostRegister keeps free() valid for the
+       * caller) and copy each song straight to its place in the arena */
+      for (size_t i = 0; i < desc.size() && rc == BL_OK; ++i) {
+        void *hp = const_cast<void *>(h_pcm[begin + i]);
+        const size_t nb = (size_t)desc[i].n_samples * 2;
+        if (hipHostRegister(hp, nb, hipHostRegisterDefault) == hipSuccess) c->registered[k].push_back(hp);
+        else (void)hipGetLastError(); /* already registered / unpinnable: the copy still works, staged by the runtime */
+        if (hipMemcpyAsync(d_arena + desc[i].pcm_offset, hp, nb, hipMemcpyHostToDevice, s) != hipSuccess)
+          rc = BL_UNEXPECTED;
+      }
+      if (rc != BL_OK) break;
+    } else {
+      if (c->pinned_cap[k] < bytes) {
+        if (c->pinned[k]) (void)hipHostFree(c->pinned[k]);
+        c->pinned[k] = nullptr; c->pinned_cap[k] = 0;
+        if (hipHostMalloc(&c->pinned[k], bytes, hipHostMallocDefault) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+        c->pinned_cap[k] = bytes;
+      }
+      int16_t *stage = static_cast<int16_t *>(c->pinned[k]);
+      /* staging copy on several host threads: one thread moves ~10 GB/s, the link takes more.
+       * 32-bit sources are narrowed here (>> 16), so the link only ever carries s16. */
+      const int n_thr = (int)std::min<size_t>(BL_STAGE_THREADS, std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
+      auto copy_range = [&](int t) {
+        for (size_t i = (size_t)t; i < desc.size(); i += (size_t)n_thr) {
+          int16_t *dst = stage + desc[i].pcm_offset;
+          const size_t n = (size_t)desc[i].n_samples;
+          if (pcm_is_s32) {
+            const int32_t *src = static_cast<const int32_t *>(h_pcm[begin + i]);
+            for (size_t j = 0; j < n; ++j) dst[j] = (int16_t)(src[j] >> 16);
+          } else {
+            memcpy(dst, h_pcm[begin + i], n * 2);
+          }
+          const size_t padded = (n + 7) & ~(size_t)7;
+          for (size_t z = n; z < padded; ++z) dst[z] = 0;
+        }
+      };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < n_thr; ++t) pool.emplace_back(copy_range, t);
+      copy_range(0);
+      for (auto &th : pool) th.join();
+      if (hipMemcpyAsync(d_arena, stage, elems * 2, hipMemcpyHostToDevice, s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+    }
+    if (blr_analyze_device(c, d_arena, desc.data(), (int)desc.size(), d_res + begin, s, 7) != BL_OK) {
+      rc = BL_UNEXPECTED;
+      break;
+    }
+    if (hipEventRecord(done[k], s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+    used[k] = true;
+    begin = end;
+    ++wave;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (c->streams[k] && hipStreamSynchronize(c->streams[k]) != hipSuccess) rc = BL_UNEXPECTED;
+    unregister_wave(c, k);
+    (void)hipEventDestroy(done[k]);
+  }
+  if (rc == BL_OK && h_results &&
+      hipMemcpy(h_results, d_res, sizeof(bl_amd_song_result) * (size_t)n_songs, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = BL_UNEXPECTED;
+  if (d_res_out) *d_res_out = d_res;
+  return rc;
+}
+
+/* ========================================================================= */
+/* C-ABI                                                                      */
+
+extern "C" {
+
+int bl_amd_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+int bl_amd_init(int device) {
+  const int prev = tl_device;
+  tl_device = device;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) {
+    tl_device = prev;
+    return BL_UNEXPECTED;
+  }
+  int expect = -1;
+  g_process_device.compare_exchange_strong(expect, device);
+  return BL_OK;
+}
+
+int bld_ready(void) { return blr_default_ctx() ? BL_OK : BL_UNEXPECTED; }
+
+int bl_amd_ctx_create(int device, bl_amd_ctx **out) {
+  if (!out) return BL_UNEXPECTED;
+  *out = nullptr;
+  bl_amd_ctx *c = new bl_amd_ctx();
+  if (ctx_init(c, device) != BL_OK) {
+    ctx_release(c);
+    delete c;
+    return BL_UNEXPECTED;
+  }
+  *out = c;
+  return BL_OK;
+}
+
+void bl_amd_ctx_destroy(bl_amd_ctx *ctx) {
+  if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx_release(ctx);
+  }
+  delete ctx;
+}
+
+int bl_amd_ctx_device(const bl_amd_ctx *ctx) { return ctx ? ctx->device : BL_UNEXPECTED; }
+
+void bl_amd_profile(int enable) {
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->prof = enable != 0;
+}
+
+void bl_amd_profile_reset(void) {
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  prof_collect(c);
+  for (int k = 0; k < PK_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+}
+
+double bl_amd_profile_ms(const char *name, int *launches) {
+  static const char *const kProfNames[PK_COUNT] = {"pcm_scan",    "amp_finish", "freq_frames", "freq_finish",
+                                                   "env_windows", "env_tail",   "distance"};
+  if (launches) *launches = 0;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c || !name) return -1.0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  prof_collect(c);
+  for (int k = 0; k < PK_COUNT; ++k)
+    if (!strcmp(name, kProfNames[k])) {
+      if (launches) *launches = c->prof_n[k];
+      return c->prof_ms[k];
+    }
+  return -1.0;
+}
+
+int bl_amd_ctx_analyze_batch_device(bl_amd_ctx *ctx, const int16_t *d_pcm, const bl_amd_song_desc *h_desc,
+                                    int n_songs, bl_amd_song_result *d_results, void *stream) {
+  if (!ctx || n_songs <= 0 || !d_pcm || !h_desc || !d_results) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DevGuard dg(ctx->device);
+  if (!dg.ok) return BL_UNEXPECTED;
+  return blr_analyze_device(ctx, d_pcm, h_desc, n_songs, d_results, static_cast<hipStream_t>(stream), 7);
+}
+
+int bl_amd_analyze_batch_device(const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
+                                bl_amd_song_result *d_results, void *stream) {
+  return bl_amd_ctx_analyze_batch_device(blr_default_ctx(), d_pcm, h_desc, n_songs, d_results, stream);
+}
+
+int bl_amd_synth_pcm_device(int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
+                            uint32_t seed_base, uint32_t sample_rate, void *stream) {
+  if (n_songs <= 0 || !d_pcm || !h_desc) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int i = 0; i < n_songs; ++i)
+    if (validate_desc(h_desc[i], i) != BL_OK) return BL_UNEXPECTED;
+  /* the descriptor block of the workspace is shared with the analysis: same hand-over */
+  if (c->ws_used) BL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ws, 0));
+  if (blr_ensure(c->songs, sizeof(bl_dsong) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
+  bl_pin_slot *slot = nullptr;
+  if (ring_get(c, sizeof(bl_dsong) * (size_t)n_songs, &slot) != BL_OK) return BL_UNEXPECTED;
+  bl_dsong *hs = static_cast<bl_dsong *>(slot->p);
+  const int G = BL_GROUP_SONGS_MAX;
+  std::vector<int> max_n((n_songs + G - 1) / G);
+  for (int b = 0, gi = 0; b < n_songs; b += G, ++gi) {
+    long long env_total;
+    fill_group(h_desc + b, std::min(G, n_songs - b), hs + b, env_total, max_n[gi]);
+  }
+  bl_dsong *d_songs = static_cast<bl_dsong *>(c->songs.p);
+  BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs, sizeof(bl_dsong) * (size_t)n_songs, hipMemcpyHostToDevice, s));
+  BL_HIP_CHECK(hipEventRecord(slot->ev, s));
+  slot->busy = true;
+  for (int b = 0, gi = 0; b < n_songs; b += G, ++gi)
+    if (blk_synth(s, d_pcm, d_songs + b, std::min(G, n_songs - b), max_n[gi], c->n_cu,
+                  seed_base + (uint32_t)b, sample_rate) != BL_OK)
+      return BL_UNEXPECTED;
+  BL_HIP_CHECK(hipEventRecord(c->ev_ws, s));
+  c->ws_used = true;
+  return BL_OK;
+}
+
+static int matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin, int n_rows,
+                         float *d_out, void *stream, bool cosine) {
+  if (n <= 0 || n_rows <= 0 || row_begin < 0 || row_begin + n_rows > n || !d_vecs || !d_out)
+    return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  return blk_pairwise(static_cast<hipStream_t>(stream), d_vecs, n, row_begin, n_rows, d_out, cosine,
+                      c->prof ? mark_cb : nullptr, c);
+}
+
+int bl_amd_distance_matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin,
+                                  int n_rows, float *d_out, void *stream) {
+  return matrix_device(d_vecs, n, row_begin, n_rows, d_out, stream, false);
+}
+
+int bl_amd_cosine_matrix_device(const struct force_vector_s *d_vecs, int n, int row_begin,
+                                int n_rows, float *d_out, void *stream) {
+  return matrix_device(d_vecs, n, row_begin, n_rows, d_out, stream, true);
+}
+
+int bl_amd_playlist_device(const struct force_vector_s *d_vecs, int n, int seed_index,
+                           int32_t *d_order, float *d_dist, void *stream) {
+  if (n <= 0 || seed_index < 0 || seed_index >= n || !d_vecs || !d_order || !d_dist)
+    return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  DevGuard dg(c->device);
+  return blk_playlist(static_cast<hipStream_t>(stream), d_vecs, n, seed_index, d_order, d_dist);
+}
+
+int bl_amd_playlist_host(const struct force_vector_s *h_vecs, int n, int seed_index,
+                         int32_t *h_order, float *h_dist) {
+  if (n <= 0 || !h_vecs || !h_order) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  DevGuard dg(c->device);
+  void *dv = nullptr, *dord = nullptr, *dd = nullptr;
+  int rc = BL_UNEXPECTED;
+  if (hipMalloc(&dv, sizeof(struct force_vector_s) * (size_t)n) == hipSuccess &&
+      hipMalloc(&dord, sizeof(int32_t) * (size_t)n) == hipSuccess &&
+      hipMalloc(&dd, sizeof(float) * (size_t)n) == hipSuccess &&
+      hipMemcpy(dv, h_vecs, sizeof(struct force_vector_s) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+      bl_amd_playlist_device(static_cast<struct force_vector_s *>(dv), n, seed_index,
+                             static_cast<int32_t *>(dord), static_cast<float *>(dd), nullptr) == BL_OK &&
+      hipMemcpy(h_order, dord, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess &&
+      (!h_dist || hipMemcpy(h_dist, dd, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess))
+    rc = BL_OK;
+  if (dv) (void)hipFree(dv);
+  if (dord) (void)hipFree(dord);
+  if (dd) (void)hipFree(dd);
+  return rc;
+}
+
+static int matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out, bool cosine) {
+  if (n <= 0 || !h_vecs || !h_out) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  DevGuard dg(c->device);
+  void *dv = nullptr, *dout = nullptr;
+  BL_HIP_CHECK(hipMalloc(&dv, sizeof(struct force_vector_s) * (size_t)n));
+  if (hipMalloc(&dout, sizeof(float) * (size_t)n * n) != hipSuccess) { (void)hipFree(dv); return BL_UNEXPECTED; }
+  int rc = BL_UNEXPECTED;
+  if (hipMemcpy(dv, h_vecs, sizeof(struct force_vector_s) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+      matrix_device(static_cast<struct force_vector_s *>(dv), n, 0, n, static_cast<float *>(dout),
+                    nullptr, cosine) == BL_OK &&
+      hipMemcpy(h_out, dout, sizeof(float) * (size_t)n * n, hipMemcpyDeviceToHost) == hipSuccess)
+    rc = BL_OK;
+  (void)hipFree(dv);
+  (void)hipFree(dout);
+  return rc;
+}
+
+int bl_amd_distance_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out) {
+  return matrix_host(h_vecs, n, h_out, false);
+}
+int bl_amd_cosine_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out) {
+  return matrix_host(h_vecs, n, h_out, true);
+}
+
+int bl_amd_set_host_transfer(int mode) {
+  if (mode != BL_AMD_HOST_STAGED && mode != BL_AMD_HOST_REGISTERED) return BL_UNEXPECTED;
+  g_host_mode.store(mode);
+  return BL_OK;
+}
+
+int bl_amd_ctx_analyze_batch_host(bl_amd_ctx *ctx, const int16_t *const *h_pcm, const int32_t *n_samples,
+                                  const int32_t *channels, const uint64_t *duration, int n_songs,
+                                  bl_amd_song_result *h_results) {
+  if (!ctx || n_songs <= 0 || !h_pcm || !n_samples || !channels || !duration || !h_results)
+    return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DevGuard dg(ctx->device);
+  if (!dg.ok) return BL_UNEXPECTED;
+  return blr_analyze_host(ctx, reinterpret_cast<const void *const *>(h_pcm), 0, n_samples, channels,
+                          duration, n_songs, h_results, nullptr);
+}
+
+int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samples,
+                              const int32_t *channels, const uint64_t *duration, int n_songs,
+                              bl_amd_song_result *h_results) {
+  return bl_amd_ctx_analyze_batch_host(blr_default_ctx(), h_pcm, n_samples, channels, duration, n_songs,
+                                       h_results);
+}
+
+int bl_amd_analyze_batch_host_s32(const int32_t *const *h_pcm, const int32_t *n_samples,
+                                  const int32_t *channels, const uint64_t *duration, int n_songs,
+                                  bl_amd_song_result *h_results) {
+  if (n_songs <= 0 || !h_pcm || !n_samples || !channels || !duration || !h_results) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  return blr_analyze_host(c, reinterpret_cast<const void *const *>(h_pcm), 1, n_samples, channels,
+                          duration, n_songs, h_results, nullptr);
+}
+
+int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void *stream) {
+  if (!d_in || !d_out) return BL_UNEXPECTED;
+  if (n == 0) return BL_OK;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  DevGuard dg(c->device);
+  return blk_narrow_s32(static_cast<hipStream_t>(stream), d_in, d_out, n, c->n_cu);
+}
+
+/* ---- helpers behind the reference-API shims of bl_api.c ---- */
+int bld_analyze_one_host(const int16_t *h_pcm, int n, int channels, uint64_t duration, int what,
+                         bl_amd_song_result *res) {
+  if (!h_pcm || !res) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  if (!c->streams[0]) BL_HIP_CHECK(hipStreamCreateWithFlags(&c->streams[0], hipStreamNonBlocking));
+  hipStream_t s = c->streams[0];
+  const size_t elems = ((size_t)n + 7) & ~(size_t)7;
+  if (blr_ensure(c->arena[0], elems * 2 + 64) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->results, sizeof(bl_amd_song_result)) != BL_OK) return BL_UNEXPECTED;
+  if (c->ws_used) BL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ws, 0));
+  BL_HIP_CHECK(hipMemcpyAsync(c->arena[0].p, h_pcm, (size_t)n * 2, hipMemcpyHostToDevice, s));
+  BL_HIP_CHECK(hipMemsetAsync(c->results.p, 0, sizeof(bl_amd_song_result), s));
+  bl_amd_song_desc d;
+  d.pcm_offset = 0; d.n_samples = n; d.channels = channels; d.duration = duration;
+  if (blr_analyze_device(c, static_cast<const int16_t *>(c->arena[0].p), &d, 1,
+                         static_cast<bl_amd_song_result *>(c->results.p), s, what) != BL_OK)
+    return BL_UNEXPECTED;
+  BL_HIP_CHECK(hipMemcpyAsync(res, c->results.p, sizeof(bl_amd_song_result), hipMemcpyDeviceToHost, s));
+  BL_HIP_CHECK(hipStreamSynchronize(s));
+  return BL_OK;
+}
+
+int bld_mean_variance_host(const int16_t *h_pcm, int n, int have_mean, int mean_in, int *mean_out,
+                           int *variance_out) {
+  if (!h_pcm || n <= 0) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  if (!c->streams[0]) BL_HIP_CHECK(hipStreamCreateWithFlags(&c->streams[0], hipStreamNonBlocking));
+  hipStream_t s = c->streams[0];
+  const size_t elems = ((size_t)n + 7) & ~(size_t)7;
+  if (blr_ensure(c->arena[0], elems * 2 + 64) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->songs, sizeof(bl_dsong)) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->stats, sizeof(bl_dstats)) != BL_OK) return BL_UNEXPECTED;
+  if (blr_ensure(c->hist, sizeof(unsigned) * BL_HIST_BINS) != BL_OK) return BL_UNEXPECTED;
+  /* same workspace as the batches: wait for the previous user on the device, hand it on after */
+  if (c->ws_used) BL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ws, 0));
+  BL_HIP_CHECK(hipMemcpyAsync(c->arena[0].p, h_pcm, (size_t)n * 2, hipMemcpyHostToDevice, s));
+  bl_pin_slot *slot = nullptr;
+  if (ring_get(c, sizeof(bl_dsong), &slot) != BL_OK) return BL_UNEXPECTED;
+  bl_dsong *hs = static_cast<bl_dsong *>(slot->p);
+  memset(hs, 0, sizeof *hs);
+  hs->n = n; hs->channels = 1; hs->duration = 1;
+  BL_HIP_CHECK(hipMemcpyAsync(c->songs.p, hs, sizeof *hs, hipMemcpyHostToDevice, s));
+  BL_HIP_CHECK(hipEventRecord(slot->ev, s));
+  slot->busy = true;
+  bl_dstats *d_stats = static_cast<bl_dstats *>(c->stats.p);
+  const bl_dsong *d_songs = static_cast<const bl_dsong *>(c->songs.p);
+  const int16_t *d_pcm = static_cast<const int16_t *>(c->arena[0].p);
+  if (blk_scan_one(s, d_pcm, d_songs, d_stats, static_cast<unsigned *>(c->hist.p), n, c->n_cu) != BL_OK)
+    return BL_UNEXPECTED;
+  bl_dstats st;
+  BL_HIP_CHECK(hipMemcpyAsync(&st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));
+  BL_HIP_CHECK(hipStreamSynchronize(s));
+  /* ref helpers.c:30-37 */
+  const int mean = have_mean ? mean_in : (int)(unsigned)(st.sum & 0xFFFFFFFFull) / n;
+  if (mean_out) *mean_out = mean;
+  if (variance_out) {
+    /* always the exact wrapping form (ref helpers.c:39-49) for the stand-alone helper */
+    st.mean = mean; st.wrap_pass = 1; st.wrap_acc = 0;
+    BL_HIP_CHECK(hipMemcpyAsync(d_stats, &st, sizeof st, hipMemcpyHostToDevice, s));
+    if (blk_variance_wrap_one(s, d_pcm, d_songs, d_stats, n, c->n_cu) != BL_OK) return BL_UNEXPECTED;
+    BL_HIP_CHECK(hipMemcpyAsync(&st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));
+    BL_HIP_CHECK(hipStreamSynchronize(s));
+    *variance_out = (int)(st.wrap_acc / n);
+  }
+  BL_HIP_CHECK(hipEventRecord(c->ev_ws, s));
+  c->ws_used = true;
+  return BL_OK;
+}
+
+/* diagnostic: the per-window energies (ref tempo_atk_sort.c:150, filtered_array) of the
+ * most recent launch group, songs concatenated, nb_frames slots per song (last two unused) */
+long long bl_amd_last_energies(float *h_out, long long max_elems) {
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return -1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  if (!c->energies.p || c->last_env_total <= 0) return 0;
+  const long long n = c->last_env_total < max_elems ? c->last_env_total : max_elems;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(h_out, c->energies.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return n;
+}
+
+void bl_multi_shutdown(void); /* bl_multi.hip */
+
+void bl_amd_shutdown(void) {
+  bl_multi_shutdown();
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int d = 0; d < BL_MAX_DEVICES; ++d) {
+    if (!g_default[d]) continue;
+    {
+      std::lock_guard<std::mutex> lk2(g_default[d]->mu);
+      ctx_release(g_default[d]);
+    }
+    delete g_default[d];
+    g_default[d] = nullptr;
+  }
+}
+
+} /* extern "C" */

@@ -53,19 +53,35 @@ typedef struct bl_amd_song_result {
   double atk_sum;          /* ref src/tempo_atk_sort.c:246-248 */
 } bl_amd_song_result;
 
-/* Select / initialise the HIP device used by this process (default 0). */
+/* Select the HIP device the plain entry points below use ON THE CALLING THREAD and create
+ * its default context (workspace, internal streams).  The first call of the process also
+ * sets the process default, which threads that never called bl_amd_init use (device 0 if
+ * nobody did).  One process can drive several GPUs: one thread per device. */
 int bl_amd_init(int device);
 /* Number of visible HIP devices (0 if none / no runtime). */
 int bl_amd_device_count(void);
 
+/* Explicit contexts: one device, an own scratch workspace, own internal streams and pinned
+ * staging.  Calls on one context are ordered; different contexts — also on the same device —
+ * are independent and may be driven from different host threads concurrently. */
+typedef struct bl_amd_ctx bl_amd_ctx;
+int bl_amd_ctx_create(int device, bl_amd_ctx **out);
+void bl_amd_ctx_destroy(bl_amd_ctx *ctx);
+int bl_amd_ctx_device(const bl_amd_ctx *ctx);
+
 /* Analyse n_songs songs whose PCM already sits in device memory.
- * d_pcm: arena base; h_desc: host array of n_songs descriptors;
- * d_results: device array of n_songs results (written asynchronously on
- * `stream`).  Scratch comes from an internal, growing device workspace that all calls
- * share: batches enqueued on different streams are ordered on the device (each waits
- * for the previous one to finish with the workspace), they do not overlap. */
+ * d_pcm: arena base; h_desc: host array of n_songs descriptors (copied before the call
+ * returns); d_results: device array of n_songs results, written asynchronously on `stream`.
+ * The call only enqueues work (descriptor upload from pinned memory, kernels); it does not
+ * wait for the device unless the workspace has to grow or four earlier batches of the
+ * context are still in flight.  Scratch comes from the context's growing workspace: batches
+ * of one context enqueued on different streams are ordered on the device (each waits for the
+ * previous one to finish with the workspace); batches of different contexts overlap. */
 int bl_amd_analyze_batch_device(const int16_t *d_pcm, const bl_amd_song_desc *h_desc,
                                 int n_songs, bl_amd_song_result *d_results, void *stream);
+int bl_amd_ctx_analyze_batch_device(bl_amd_ctx *ctx, const int16_t *d_pcm,
+                                    const bl_amd_song_desc *h_desc, int n_songs,
+                                    bl_amd_song_result *d_results, void *stream);
 
 /* Same from host memory: stages PCM through pinned buffers with
  * hipMemcpyAsync overlapped against the kernels of the previous wave of
@@ -73,6 +89,59 @@ int bl_amd_analyze_batch_device(const int16_t *d_pcm, const bl_amd_song_desc *h_
 int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samples,
                               const int32_t *channels, const uint64_t *duration, int n_songs,
                               bl_amd_song_result *h_results);
+int bl_amd_ctx_analyze_batch_host(bl_amd_ctx *ctx, const int16_t *const *h_pcm,
+                                  const int32_t *n_samples, const int32_t *channels,
+                                  const uint64_t *duration, int n_songs,
+                                  bl_amd_song_result *h_results);
+/* How host buffers reach the device: BL_AMD_HOST_STAGED copies them into the library's pinned
+ * double buffers on several host threads (default); BL_AMD_HOST_REGISTERED pins the caller's
+ * buffers in place with hipHostRegister for the duration of the call (free() stays valid,
+ * SURVEY.md section 8b) and copies each song straight into the arena.  Also settable with
+ * the environment variable BL_AMD_HOST_MODE=staged|registered. */
+#define BL_AMD_HOST_STAGED 0
+#define BL_AMD_HOST_REGISTERED 1
+int bl_amd_set_host_transfer(int mode);
+
+/* 32-bit sources (BASELINE configs[4] "s16/s32"): h_pcm[i] holds n_samples[i] interleaved
+ * int32 samples; they reach the hot path as s16 through an arithmetic >> 16 — the same-rate
+ * S32 -> S16 conversion the reference gets from libswresample (ref src/decode.c:323-346,
+ * 388-392; third-party arithmetic, parity unpinned).  The narrowing happens while the songs
+ * are staged, so the PCIe link only carries s16. */
+int bl_amd_analyze_batch_host_s32(const int32_t *const *h_pcm, const int32_t *n_samples,
+                                  const int32_t *channels, const uint64_t *duration, int n_songs,
+                                  bl_amd_song_result *h_results);
+/* The same narrowing for a device-resident int32 buffer: d_out[i] = (int16)(d_in[i] >> 16). */
+int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void *stream);
+
+/* Batch-of-songs mode across the GPUs of one node (BASELINE configs[2]): the corpus is
+ * sharded by song over the ranks listed in `devices` (one host thread and one context per
+ * rank: contiguous blocks for equal lengths, longest-first greedy by sample count
+ * otherwise), each rank analyses its shard through the host-batch path, the 16-byte force
+ * vectors are all-gathered (flags: BL_AMD_MULTI_GATHER_RCCL = ncclAllGather over xGMI,
+ * librccl loaded on first use; BL_AMD_MULTI_GATHER_PEER = direct peer copies, which also
+ * permits several ranks on one device) and rank r computes rows [r N / W, (r+1) N / W) of
+ * the N x N bl_distance matrix in the caller's song order.  h_results: n_songs records in
+ * caller order.  h_matrix: NULL, or n_songs * n_songs floats that receive the row blocks.
+ * Blocking. */
+#define BL_AMD_MULTI_GATHER_RCCL 0
+#define BL_AMD_MULTI_GATHER_PEER 1
+int bl_amd_analyze_corpus_multi(const int16_t *const *h_pcm, const int32_t *n_samples,
+                                const int32_t *channels, const uint64_t *duration, int n_songs,
+                                const int *devices, int n_devices, int flags,
+                                bl_amd_song_result *h_results, float *h_matrix);
+
+/* bl_audio_decode() follows the reference in always presenting 22 050 Hz PCM to the
+ * analyzers (ref src/decode.c:7-9,317-346), but it has no resampler (libswresample's
+ * arithmetic cannot be reproduced here): a file at another rate fails with BL_UNEXPECTED
+ * unless the caller opts in to analysing it at its native rate (allow != 0; also
+ * BL_AMD_ALLOW_NATIVE_RATE=1).  Force vectors of such files are not comparable with the
+ * reference's. */
+void bl_amd_decode_allow_native_rate(int allow);
+/* Integrity check of the FLAC decoder behind bl_audio_decode: decodes `filename` and compares
+ * the MD5 of the decoded samples at their native width (before the narrowing to s16) with the
+ * signature of the unencoded audio in the file's STREAMINFO block.  1 = match, 0 = mismatch,
+ * BL_UNEXPECTED = not decodable.  computed / stored (16 bytes each) may be NULL. */
+int bl_amd_flac_verify(const char *filename, uint8_t computed[16], uint8_t stored[16]);
 
 /* Rows [row_begin, row_begin + n_rows) of the N x N bl_distance matrix
  * (ref src/analyze.c:96-100 for every pair).  d_out: n_rows * n floats. */
@@ -114,7 +183,8 @@ double bl_amd_profile_ms(const char *name, int *launches);
  * max_elems floats to h_out; returns the number copied, 0 if none, -1 on error. */
 long long bl_amd_last_energies(float *h_out, long long max_elems);
 
-/* Releases the workspace, streams and pinned staging buffers. */
+/* Releases every default context (workspaces, streams, pinned staging) and the multi-device
+ * state.  Explicit contexts are released by bl_amd_ctx_destroy. */
 void bl_amd_shutdown(void);
 
 #ifdef __cplusplus

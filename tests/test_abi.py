@@ -40,13 +40,50 @@ def test_struct_layout_matches_reference():
 
 
 def test_no_device_fails_loudly(lib):
+    """No CPU path behind the analysis: every analysis entry point reports BL_UNEXPECTED."""
+    import numpy as np
     import torch
     if torch.cuda.is_available():
         return
     assert lib.bl_amd_device_count() == 0
     assert lib.bl_amd_init(0) == _lib.BL_UNEXPECTED
-    a = _lib.ForceVector(1, 2, 3, 4)
-    assert lib.bl_distance(a, a) == float(_lib.BL_UNEXPECTED)  # no CPU path behind it
+    pcm = np.ones(8192, dtype=np.int16)
+    song = _lib.BlSong()
+    song.sample_array = pcm.ctypes.data
+    song.nSamples, song.channels, song.duration = pcm.size, 1, 1
+    assert lib.bl_amplitude_sort(C.byref(song)) == float(_lib.BL_UNEXPECTED)
+    assert lib.bl_frequency_sort(C.byref(song)) == float(_lib.BL_UNEXPECTED)
+    env = _lib.EnvelopeResult()
+    lib.bl_envelope_sort(C.byref(song), C.byref(env))
+    assert env.tempo == float(_lib.BL_UNEXPECTED)
+    assert lib.bl_mean(pcm.ctypes.data_as(C.POINTER(C.c_int16)), pcm.size) == _lib.BL_UNEXPECTED
+    s2 = _lib.BlSong()
+    flac = os.path.join(ROOT, "tests", "golden", "song.flac").encode()
+    assert lib.bl_analyze(flac, C.byref(s2)) == _lib.BL_UNEXPECTED   # decodes, then no device
+    lib.bl_free_song(C.byref(s2))
+    with __import__("pytest").raises(RuntimeError):
+        bliss_amd.analyze_batch_host([pcm], 1, 1)
+    ctx = C.c_void_p()
+    assert lib.bl_amd_ctx_create(0, C.byref(ctx)) == _lib.BL_UNEXPECTED and not ctx.value
+
+
+def test_scalar_helpers_are_the_reference_expressions(lib, oracle):
+    """bl_distance / bl_cosine_similarity of one pair and bl_rectangular_filter are host
+    arithmetic (bl_api.c); bit-identical to the oracle here, and to the GPU's all-pairs kernels
+    in tests/test_gpu_parity.py."""
+    import numpy as np
+    rng = np.random.default_rng(8)
+    v = (rng.standard_normal((64, 4)) * 10).astype(np.float32)
+    for i in range(0, 64, 2):
+        a, b = _lib.ForceVector(*v[i]), _lib.ForceVector(*v[i + 1])
+        assert lib.bl_distance(a, b) == oracle.distance(v[i], v[i + 1])
+        assert lib.bl_cosine_similarity(a, b) == oracle.cosine(v[i], v[i + 1])
+    dp = C.POINTER(C.c_double)
+    for n, w in ((500, 19), (20, 19), (40, 19), (64, 7)):
+        inp, old = rng.standard_normal(n), rng.standard_normal(n)
+        out = old.copy()
+        lib.bl_rectangular_filter(out.ctypes.data_as(dp), inp.ctypes.data_as(dp), n, w)
+        assert np.array_equal(out, oracle.rect_filter(old, inp, w)), (n, w)
 
 
 def test_return_codes():

@@ -1,0 +1,173 @@
+"""Host ingest (bl_audio_decode) beyond the 16-bit fixture: 24-bit FLAC pinned by the STREAMINFO
+signature of the reference's own audio/song_s32*.flac, the S32 -> S16 narrowing, the sample-rate
+policy, WAV 24/32-bit, and malformed metadata.  No GPU involved."""
+import ctypes as C
+import hashlib
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from bliss_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _crc8(data):
+    c = 0
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = ((c << 1) ^ 0x07) & 0xFF if c & 0x80 else (c << 1) & 0xFF
+    return c
+
+
+def _crc16(data):
+    c = 0
+    for b in data:
+        c ^= b << 8
+        for _ in range(8):
+            c = ((c << 1) ^ 0x8005) & 0xFFFF if c & 0x8000 else (c << 1) & 0xFFFF
+    return c
+
+
+def write_flac_verbatim(path, samples, channels, rate, bps, comment_block=None):
+    """Minimal FLAC writer (VERBATIM subframes, independent channels, one frame per 4096
+    samples): test input for the decoder, bit depth 16 or 24."""
+    samples = np.asarray(samples, dtype=np.int64).reshape(-1, channels)
+    total = samples.shape[0]
+    nb = bps // 8
+    raw = b"".join(int(v).to_bytes(nb, "little", signed=True) for v in samples.reshape(-1))
+    md5 = hashlib.md5(raw).digest()
+    info = struct.pack(">HH", 4096, 4096) + b"\0\0\0" + b"\0\0\0"
+    packed = (rate << 44) | ((channels - 1) << 41) | ((bps - 1) << 36) | total
+    info += packed.to_bytes(8, "big") + md5
+    blocks = [(0, info)]
+    if comment_block is not None:
+        blocks.append((4, comment_block))
+    out = bytearray(b"fLaC")
+    for i, (t, body) in enumerate(blocks):
+        last = 0x80 if i == len(blocks) - 1 else 0
+        out += bytes([last | t]) + len(body).to_bytes(3, "big") + body
+    ss_code = {16: 4, 24: 6}[bps]
+    for fno, start in enumerate(range(0, total, 4096)):
+        blk = samples[start:start + 4096]
+        bs = blk.shape[0]
+        hdr = bytearray([0xFF, 0xF8])
+        hdr.append((7 << 4) | 0)                       # blocksize: 16-bit field follows; rate: from STREAMINFO
+        hdr.append(((channels - 1) << 4) | (ss_code << 1))
+        assert fno < 128
+        hdr.append(fno)                                # UTF-8 coded frame number (1 byte)
+        hdr += (bs - 1).to_bytes(2, "big")
+        hdr.append(_crc8(hdr))
+        bits = []
+        for c in range(channels):
+            bits.append("0" + "000001" + "0")          # padding, VERBATIM, no wasted bits
+            for v in blk[:, c]:
+                bits.append(format(int(v) & ((1 << bps) - 1), "0%db" % bps))
+        s = "".join(bits)
+        s += "0" * (-len(s) % 8)
+        frame = bytes(hdr) + int(s, 2).to_bytes(len(s) // 8, "big")
+        out += frame + _crc16(frame).to_bytes(2, "big")
+    open(path, "wb").write(bytes(out))
+    return md5
+
+
+def _decode(lib, path):
+    song = _lib.BlSong()
+    rc = lib.bl_audio_decode(str(path).encode(), C.byref(song))
+    if rc != _lib.BL_OK:
+        return rc, None, None
+    pcm = np.ctypeslib.as_array(C.cast(song.sample_array, C.POINTER(C.c_int16)), shape=(song.nSamples,)).copy()
+    meta = dict(channels=song.channels, rate=song.sample_rate, duration=song.duration,
+                nb=song.nb_bytes_per_sample, resampled=song.resampled, title=song.title)
+    lib.bl_free_song(C.byref(song))
+    return rc, pcm, meta
+
+
+@pytest.mark.parametrize("name,stored", [
+    ("song.flac", "8a1bd824951c0433cc47fec5bf41d0a9"),      # == ref tests/test_decode.c:16-17
+    ("song_s32.flac", None), ("song_s32_mono.flac", None)])
+def test_flac_decoder_matches_streaminfo_signature(lib, name, stored):
+    """The MD5 of the decoded samples at native width equals the signature the encoder stored:
+    pins the 24-bit path of the decoder on the reference's own fixtures."""
+    got = (C.c_uint8 * 16)()
+    want = (C.c_uint8 * 16)()
+    assert lib.bl_amd_flac_verify(os.path.join(GOLD, name).encode(), got, want) == 1
+    assert bytes(got) == bytes(want) and any(bytes(want))
+    if stored:
+        assert bytes(got).hex() == stored
+
+
+def test_sample_rate_policy(lib):
+    """48 kHz sources: the reference resamples to 22 050 Hz (ref src/decode.c:317-346); this
+    library cannot and must say so instead of analysing at the wrong rate."""
+    p = os.path.join(GOLD, "song_s32.flac")
+    lib.bl_amd_decode_allow_native_rate(0)
+    rc, _, _ = _decode(lib, p)
+    assert rc == _lib.BL_UNEXPECTED
+    lib.bl_amd_decode_allow_native_rate(1)
+    try:
+        rc, pcm, meta = _decode(lib, p)
+        assert rc == _lib.BL_OK and meta["rate"] == 48000 and meta["channels"] == 2
+        assert meta["nb"] == 2 and meta["resampled"] == 0 and meta["duration"] == 11
+        assert pcm.size == 2 * 531307 and meta["title"] == b"Renaissance"
+        rc, mono, meta = _decode(lib, os.path.join(GOLD, "song_s32_mono.flac"))
+        assert rc == _lib.BL_OK and meta["channels"] == 1 and mono.size == 531307
+    finally:
+        lib.bl_amd_decode_allow_native_rate(0)
+
+
+def test_24bit_flac_is_narrowed_with_shift(lib, tmp_path):
+    rng = np.random.default_rng(3)
+    s24 = rng.integers(-(1 << 23), 1 << 23, 2 * 9000)
+    s24[:4] = [(1 << 23) - 1, -(1 << 23), -1, 255]
+    p = tmp_path / "v24.flac"
+    md5 = write_flac_verbatim(p, s24, 2, 22050, 24)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["nb"] == 2 and meta["rate"] == 22050
+    # left-justified in 32 bits, arithmetic >> 16  ==  24-bit value >> 8
+    assert np.array_equal(pcm, ((s24 << 8) >> 16).astype(np.int16))
+    got = (C.c_uint8 * 16)()
+    assert lib.bl_amd_flac_verify(str(p).encode(), got, None) == 1 and bytes(got) == md5
+    s16 = rng.integers(-32768, 32768, 2 * 5000)
+    p16 = tmp_path / "v16.flac"
+    write_flac_verbatim(p16, s16, 2, 22050, 16)
+    rc, pcm, _ = _decode(lib, p16)
+    assert rc == _lib.BL_OK and np.array_equal(pcm, s16.astype(np.int16))
+
+
+def test_wav_24_and_32_bit(lib, tmp_path):
+    rng = np.random.default_rng(4)
+    n = 2 * 7000
+    s32 = rng.integers(-(1 << 31), 1 << 31, n, dtype=np.int64)
+    for bits in (24, 32):
+        vals = s32 >> (32 - bits)
+        raw = b"".join(int(v).to_bytes(bits // 8, "little", signed=True) for v in vals)
+        fmt = struct.pack("<HHIIHH", 1, 2, 22050, 22050 * 2 * bits // 8, 2 * bits // 8, bits)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(raw)) + raw
+        p = tmp_path / f"w{bits}.wav"
+        p.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+        rc, pcm, meta = _decode(lib, p)
+        assert rc == _lib.BL_OK and meta["channels"] == 2
+        assert np.array_equal(pcm, (vals >> (bits - 16)).astype(np.int16))
+
+
+def test_malformed_vorbis_comment_lengths(lib, tmp_path):
+    """Comment / vendor lengths near 2^32 must not wrap the bounds checks (heap over-read)."""
+    s16 = np.zeros(2 * 4096, dtype=np.int64)
+    s16[::3] = 1000
+    for vendor_len, comment_len in ((0, 0xFFFFFFFF), (0xFFFFFFF0, 5), (0, 0xFFFFFFF9), (3, 0x80000000)):
+        blk = struct.pack("<I", vendor_len) + b"abc"[: min(vendor_len, 3)] + struct.pack("<I", 2)
+        blk += struct.pack("<I", comment_len) + b"TITLE=x" + struct.pack("<I", 7) + b"GENRE=y"
+        p = tmp_path / "bad.flac"
+        write_flac_verbatim(p, s16, 2, 22050, 16, comment_block=blk)
+        rc, pcm, meta = _decode(lib, p)             # tags are dropped, the audio still decodes
+        assert rc == _lib.BL_OK and pcm.size == s16.size
+    good = struct.pack("<I", 3) + b"abc" + struct.pack("<I", 1) + struct.pack("<I", 9) + b"title=Hey"
+    p = tmp_path / "good.flac"
+    write_flac_verbatim(p, s16, 2, 22050, 16, comment_block=good)
+    rc, _, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["title"] == b"Hey"
