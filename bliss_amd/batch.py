@@ -75,11 +75,30 @@ class DeviceCorpus:
         assert t.numel() == self.desc[index].n_samples
         self.pcm[o:o + t.numel()].copy_(t)
 
-    def analyze(self):
-        _check(self.lib.bl_amd_analyze_batch_device(C.c_void_p(self.pcm.data_ptr()), self.desc,
-                                                    self.n_songs,
-                                                    C.c_void_p(self.results.data_ptr()),
-                                                    self._stream()), "bl_amd_analyze_batch_device")
+    def analyze(self, ctx=None):
+        """Enqueue the analysis on torch's current stream (asynchronous); ctx: an explicit
+        Context instead of the thread's default one."""
+        if ctx is None:
+            _check(self.lib.bl_amd_analyze_batch_device(C.c_void_p(self.pcm.data_ptr()), self.desc,
+                                                        self.n_songs,
+                                                        C.c_void_p(self.results.data_ptr()),
+                                                        self._stream()), "bl_amd_analyze_batch_device")
+        else:
+            _check(self.lib.bl_amd_ctx_analyze_batch_device(ctx.handle, C.c_void_p(self.pcm.data_ptr()),
+                                                            self.desc, self.n_songs,
+                                                            C.c_void_p(self.results.data_ptr()),
+                                                            self._stream()),
+                   "bl_amd_ctx_analyze_batch_device")
+
+    def upload_s32(self, index, pcm_int32):
+        """A 32-bit source: narrowed on the device (>> 16) straight into the song's slot."""
+        t = self.torch.from_numpy(np.ascontiguousarray(pcm_int32, dtype=np.int32)).to(self.device)
+        o = int(self.desc[index].pcm_offset)
+        assert t.numel() == self.desc[index].n_samples
+        dst = self.pcm[o:o + t.numel()]
+        _check(self.lib.bl_amd_narrow_s32_device(C.c_void_p(t.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                                 t.numel(), self._stream()), "bl_amd_narrow_s32_device")
+        self.torch.cuda.current_stream(self.device).synchronize()  # t may be freed on return
 
     def fetch(self):
         self.torch.cuda.synchronize(self.device)
@@ -91,11 +110,36 @@ class DeviceCorpus:
         return rec[:, :16].contiguous().view(self.torch.float32).view(self.n_songs, 4)
 
 
-def analyze_batch_host(pcm_list, channels, durations):
-    """pcm_list: list of 1-D int16 numpy arrays (interleaved).  Returns structured results."""
-    lib = _lib.load()
+class Context:
+    """An explicit library context: one device, its own workspace and internal streams.
+    Independent of the default context and of other Contexts (also on the same device)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.handle = C.c_void_p()
+        _check(self.lib.bl_amd_ctx_create(int(device), C.byref(self.handle)), "bl_amd_ctx_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.bl_amd_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def analyze_batch_host(self, pcm_list, channels, durations):
+        args, out, _keep = _host_args(pcm_list, channels, durations, np.int16)
+        _check(self.lib.bl_amd_ctx_analyze_batch_host(self.handle, *args, out),
+               "bl_amd_ctx_analyze_batch_host")
+        return results_to_numpy(bytes(out))
+
+
+def _host_args(pcm_list, channels, durations, dtype):
     n = len(pcm_list)
-    arrs = [np.ascontiguousarray(p, dtype=np.int16) for p in pcm_list]
+    arrs = [np.ascontiguousarray(p, dtype=dtype) for p in pcm_list]
     channels = [channels] * n if np.isscalar(channels) else list(channels)
     durations = [durations] * n if np.isscalar(durations) else list(durations)
     ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
@@ -103,8 +147,39 @@ def analyze_batch_host(pcm_list, channels, durations):
     chs = (C.c_int32 * n)(*channels)
     dus = (C.c_uint64 * n)(*durations)
     out = (_lib.SongResult * n)()
-    _check(lib.bl_amd_analyze_batch_host(ptrs, ns, chs, dus, n, out), "bl_amd_analyze_batch_host")
+    return (ptrs, ns, chs, dus, n), out, arrs
+
+
+def analyze_batch_host(pcm_list, channels, durations):
+    """pcm_list: list of 1-D int16 numpy arrays (interleaved).  Returns structured results."""
+    lib = _lib.load()
+    args, out, _keep = _host_args(pcm_list, channels, durations, np.int16)
+    _check(lib.bl_amd_analyze_batch_host(*args, out), "bl_amd_analyze_batch_host")
     return results_to_numpy(bytes(out))
+
+
+def analyze_batch_host_s32(pcm_list, channels, durations):
+    """Same for 32-bit sources (1-D int32 arrays): narrowed with >> 16 while they are staged."""
+    lib = _lib.load()
+    args, out, _keep = _host_args(pcm_list, channels, durations, np.int32)
+    _check(lib.bl_amd_analyze_batch_host_s32(*args, out), "bl_amd_analyze_batch_host_s32")
+    return results_to_numpy(bytes(out))
+
+
+def analyze_corpus_multi(pcm_list, channels, durations, devices, gather="rccl", matrix=True):
+    """Shard the corpus over `devices` (a rank per entry), analyse, all-gather the force vectors
+    and compute the bl_distance matrix by row blocks (bl_amd_analyze_corpus_multi).  Returns
+    (results, matrix or None), both in the caller's song order."""
+    lib = _lib.load()
+    args, out, _keep = _host_args(pcm_list, channels, durations, np.int16)
+    n = args[-1]
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    flags = {"rccl": 0, "peer": 1}[gather]
+    mat = np.empty((n, n), dtype=np.float32) if matrix else None
+    mp = mat.ctypes.data_as(C.POINTER(C.c_float)) if matrix else None
+    _check(lib.bl_amd_analyze_corpus_multi(*args, devs, len(devices), flags, out, mp),
+           "bl_amd_analyze_corpus_multi")
+    return results_to_numpy(bytes(out)), mat
 
 
 def _matrix(fn_name, vecs):

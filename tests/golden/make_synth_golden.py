@@ -17,6 +17,8 @@ from tests.oracle_py import Oracle  # noqa: E402
 CASES = [  # seed, rate, channels, seconds, extra samples
     (101, 22050, 2, 11, 0), (102, 44100, 2, 30, 0), (103, 44100, 1, 25, 123),
     (104, 22050, 1, 8, 511), (105, 48000, 2, 17, 2), (106, 8000, 1, 2, 0),
+    (107, 44100, 2, 180, 0),      # S180: the shape BASELINE.json's metric is quoted on
+    (108, 22050, 2, 600, 0),      # a 10-minute song (longest length of BASELINE configs[4])
 ]
 
 

@@ -208,10 +208,11 @@ def test_window_energies_and_full_size_sample(gpu_lib, oracle):
 
 def test_mixed_length_corpus(gpu_lib, oracle):
     """BASELINE configs[4] shape: lengths from 10 s to 10 min, mono and stereo, s16 and
-    s32 sources (s32 reaches the hot path as s16 through an arithmetic >> 16, the same-rate
-    S32->S16 conversion of the reference's resampler — parity unpinned for that step, so it
-    is applied identically before both the HIP path and the oracle).  Songs are analysed in
-    one batch in caller order; internally they are processed longest first."""
+    s32 sources.  An s32 source reaches the hot path as s16 through the library's own narrowing
+    (arithmetic >> 16, bl_amd_narrow_s32_device / bl_amd_analyze_batch_host_s32 — the same-rate
+    S32->S16 conversion of the reference's resampler, parity unpinned for that step); the oracle
+    is given numpy's >> 16 of the same words.  Songs are analysed in one batch in caller order;
+    internally they are processed longest first."""
     rng = np.random.default_rng(9)
     rate = 44100
     secs = [10, 600, 37, 75, 12, 240, 51, 18, 133, 10, 29, 64]
@@ -220,25 +221,29 @@ def test_mixed_length_corpus(gpu_lib, oracle):
     corpus = bliss_amd.DeviceCorpus(lengths, chans, secs)
     corpus.synth(seed_base=7000, sample_rate=rate)
     pcm = corpus.pcm.cpu().numpy()
-    songs = []
+    songs, wide = [], []
     for i, n in enumerate(lengths):
         o = int(corpus.desc[i].pcm_offset)
         s16 = pcm[o:o + n].copy()
         assert np.array_equal(s16[:4096], oracle.synth(7000 + i, rate, chans[i], 4096))
-        if i % 2:  # "s32 source": widen, perturb the low half, narrow back with >> 16
-            s32 = (s16.astype(np.int32) << 16) | rng.integers(0, 65536, n, dtype=np.int32)
+        s32 = s16.astype(np.int32) << 16
+        if i % 2:  # a genuine 32-bit source: the low half carries data that must be dropped
+            s32 |= rng.integers(0, 65536, n, dtype=np.int32)
+            corpus.upload_s32(i, s32)
             s16 = (s32 >> 16).astype(np.int16)
-            corpus.upload(i, s16)
         songs.append(s16)
+        wide.append(s32)
     corpus.analyze()
     got = corpus.fetch()
     for i, s16 in enumerate(songs):
         ref = oracle.analyze(s16, chans[i], secs[i])
         check_song(got[i], ref, f"mixed[{i}] {secs[i]}s x{chans[i]}")
-    # the same corpus through the host-pointer entry point (pinned staging, two streams)
+    # the same corpus through the host-pointer entry points (pinned staging, two streams)
     host = bliss_amd.analyze_batch_host(songs, chans, secs)
+    host32 = bliss_amd.analyze_batch_host_s32(wide, chans, secs)
     for k in got.dtype.names:
         assert np.array_equal(got[k], host[k]), k
+        assert np.array_equal(got[k], host32[k]), k
 
 
 def test_repeatability_and_order_independence(gpu_lib):

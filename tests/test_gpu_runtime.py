@@ -1,0 +1,185 @@
+"""Runtime behaviour of the C-ABI: explicit contexts driven from two host threads, launch
+groups, the asynchronous enqueue, registered vs staged host transfer, 32-bit sources, and the
+multi-device corpus entry point (RCCL gather at world size 1, peer gather with two ranks on one
+device)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import bliss_amd
+from bliss_amd import _lib
+from tests.test_gpu_parity import check_song
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _songs(oracle, seed0, count, rate=22050):
+    out = []
+    for i in range(count):
+        ch = 1 + (i % 2)
+        secs = 6 + (i * 5) % 9
+        out.append((oracle.synth(seed0 + i, rate, ch, rate * ch * secs + 8 * (i % 3)), ch, secs))
+    return out
+
+
+def _same(a, b):
+    for k in a.dtype.names:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_two_contexts_from_two_threads(gpu_lib, oracle):
+    """Two explicit contexts on device 0, each driven by its own host thread on its own stream,
+    several rounds concurrently: each keeps its own workspace, results match the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    sets = [_songs(oracle, 4000, 6), _songs(oracle, 4100, 7)]
+    out, err = [None, None], []
+
+    def work(t):
+        try:
+            torch.cuda.set_device(0)
+            with bliss_amd.Context(0) as ctx:
+                assert gpu_lib.bl_amd_ctx_device(ctx.handle) == 0
+                pcms = [p for p, _, _ in sets[t]]
+                corpus = bliss_amd.DeviceCorpus([p.size for p in pcms], [c for _, c, _ in sets[t]],
+                                                [d for _, _, d in sets[t]])
+                for i, p in enumerate(pcms):
+                    corpus.upload(i, p)
+                stream = torch.cuda.Stream(dev)
+                with torch.cuda.stream(stream):
+                    for _ in range(5):
+                        corpus.analyze(ctx=ctx)
+                stream.synchronize()
+                out[t] = corpus.fetch()
+        except Exception as e:  # surfaced below
+            err.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not err, err
+    for t in range(2):
+        for i, (p, c, d) in enumerate(sets[t]):
+            check_song(out[t][i], oracle.analyze(p, c, d), ("ctx", t, i))
+
+
+def test_launch_groups_and_async_enqueue(oracle, tmp_path):
+    """More songs than one launch group holds (group size lowered through the environment for a
+    fresh process) give the same records as a single group; and the device entry point returns
+    long before the GPU is done."""
+    code = r'''
+import sys, time, json
+import numpy as np
+sys.path.insert(0, %r)
+import torch, bliss_amd
+n = 22050 * 2 * 7
+c = bliss_amd.DeviceCorpus([n + 8 * (i %% 4) for i in range(13)], 2, 7)
+c.synth(seed_base=5000, sample_rate=22050)
+c.analyze(); r = c.fetch()
+big = bliss_amd.DeviceCorpus([44100 * 2 * 30] * 256, 2, 30)
+big.synth(seed_base=1, sample_rate=44100)
+big.analyze(); torch.cuda.synchronize()
+t0 = time.perf_counter(); big.analyze(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+np.save(sys.argv[1], r)
+print(json.dumps({"enqueue": t1 - t0, "total": t2 - t0}))
+''' % ROOT
+    outs = {}
+    for tag, env in (("one", {}), ("five", {"BL_AMD_GROUP_SONGS": "5"})):
+        f = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), text=True,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = (np.load(f), __import__("json").loads(r.stdout.strip().splitlines()[-1]))
+    _same(outs["one"][0], outs["five"][0])
+    ref = oracle.analyze(oracle.synth(5012, 22050, 2, 22050 * 2 * 7), 2, 7)
+    check_song(outs["five"][0][12], ref, "group-of-5, last song")
+    t = outs["one"][1]
+    assert t["enqueue"] < 0.5 * t["total"], t     # ~14 ms of kernels behind a sub-millisecond enqueue
+
+
+def test_host_transfer_modes_and_s32(gpu_lib, oracle):
+    songs = _songs(oracle, 4300, 9)
+    pcms, chans, durs = [p for p, _, _ in songs], [c for _, c, _ in songs], [d for _, _, d in songs]
+    staged = bliss_amd.analyze_batch_host(pcms, chans, durs)
+    assert gpu_lib.bl_amd_set_host_transfer(1) == 0            # hipHostRegister on the caller's buffers
+    try:
+        reg = bliss_amd.analyze_batch_host(pcms, chans, durs)
+    finally:
+        assert gpu_lib.bl_amd_set_host_transfer(0) == 0
+    _same(staged, reg)
+    assert pcms[0][0] == oracle.synth(4300, 22050, 1, 1)[0]    # the caller's memory is still its own
+    # 32-bit sources: narrowed by the library (host staging and device kernel), oracle gets numpy's >> 16
+    rng = np.random.default_rng(2)
+    s32 = [(p.astype(np.int32) << 16) | rng.integers(0, 65536, p.size, dtype=np.int32) for p in pcms]
+    got = bliss_amd.analyze_batch_host_s32(s32, chans, durs)
+    _same(staged, got)
+    corpus = bliss_amd.DeviceCorpus([p.size for p in pcms], chans, durs)
+    for i, q in enumerate(s32):
+        corpus.upload_s32(i, q)
+    corpus.analyze()
+    _same(staged, corpus.fetch())
+    for i in (0, 4, 8):
+        check_song(got[i], oracle.analyze((s32[i] >> 16).astype(np.int16), chans[i], durs[i]), ("s32", i))
+    odd = np.arange(-70000, 70001, 7, dtype=np.int32) * 30011   # unaligned views through the scalar path
+    import torch
+    t = torch.from_numpy(odd).cuda()
+    o = torch.zeros(odd.size + 3, dtype=torch.int16, device="cuda")
+    assert gpu_lib.bl_amd_narrow_s32_device(C.c_void_p(t.data_ptr() + 4), C.c_void_p(o.data_ptr() + 2),
+                                            odd.size - 1, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy()[1:odd.size], (odd[1:] >> 16).astype(np.int16))
+
+
+def test_invalid_host_descriptors_fail_before_staging(gpu_lib):
+    good = np.ones(8192, dtype=np.int16)
+    ptrs = (C.c_void_p * 2)(good.ctypes.data, None)
+    ns = (C.c_int32 * 2)(8192, 8192)
+    ch = (C.c_int32 * 2)(1, 1)
+    du = (C.c_uint64 * 2)(1, 1)
+    out = (_lib.SongResult * 2)()
+    assert gpu_lib.bl_amd_analyze_batch_host(ptrs, ns, ch, du, 2, out) == _lib.BL_UNEXPECTED   # NULL buffer
+    ptrs[1] = good.ctypes.data
+    ns[1] = -5
+    assert gpu_lib.bl_amd_analyze_batch_host(ptrs, ns, ch, du, 2, out) == _lib.BL_UNEXPECTED   # negative length
+
+
+@pytest.mark.parametrize("devices,gather", [([0], "rccl"), ([0], "peer"), ([0, 0], "peer"), ([0, 0, 0], "peer")])
+def test_corpus_multi(gpu_lib, oracle, devices, gather):
+    """The C-ABI batch-of-songs mode.  RCCL (ncclCommInitAll + ncclAllGather) runs at world size
+    1; the peer gather also takes several ranks on one device, which exercises the sharding, the
+    per-rank contexts and threads, the exchange and the row-block matrix with W = 2, 3."""
+    songs = _songs(oracle, 4500, 11)
+    for equal in (False, True):
+        use = songs if not equal else [(oracle.synth(4600 + i, 22050, 2, 22050 * 2 * 6), 2, 6) for i in range(7)]
+        pcms, chans, durs = [p for p, _, _ in use], [c for _, c, _ in use], [d for _, _, d in use]
+        res, mat = bliss_amd.analyze_corpus_multi(pcms, chans, durs, devices, gather=gather)
+        single = bliss_amd.analyze_batch_host(pcms, chans, durs)
+        _same(single, res)
+        fv = np.stack([single[k] for k in ("tempo", "amplitude", "frequency", "attack")], axis=1)
+        assert np.array_equal(mat, bliss_amd.distance_matrix(fv))
+        assert np.array_equal(mat, oracle.distance_matrix(fv))
+    res2, none = bliss_amd.analyze_corpus_multi(pcms, chans, durs, devices, gather=gather, matrix=False)
+    _same(res, res2)
+    assert none is None
+
+
+def test_scalar_helpers_match_the_kernels(gpu_lib):
+    """bl_distance / bl_cosine_similarity of one pair are host arithmetic (bl_api.c): the same
+    bits as the all-pairs kernels."""
+    rng = np.random.default_rng(31)
+    v = (rng.standard_normal((300, 4)) * 9).astype(np.float32)
+    dm, cm = bliss_amd.distance_matrix(v), bliss_amd.cosine_matrix(v)
+    for i, j in rng.integers(0, 300, (400, 2)):
+        a, b = _lib.ForceVector(*v[i]), _lib.ForceVector(*v[j])
+        assert gpu_lib.bl_distance(a, b) == dm[i, j]
+        assert gpu_lib.bl_cosine_similarity(a, b) == cm[i, j]
