@@ -36,6 +36,12 @@ template <typename T> struct bl_c2 { T re, im; };
 
 BL_HD double bl_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 BL_HD float bl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#if defined(__HIPCC__)
+/* two f32 transforms side by side (frame A in .x, frame B in .y): every operation of the
+ * templates below becomes one v_pk_*_f32 on a register pair (k_freq_frames) */
+typedef float bl_f2 __attribute__((ext_vector_type(2)));
+BL_HD bl_f2 bl_fma(bl_f2 a, bl_f2 b, bl_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 
 /* forward 4-point DFT in place: (a,b,c,d) = x0..x3 -> X0..X3, W4 = -i */
 template <typename T>
@@ -159,8 +165,9 @@ BL_HD void bl_fft512_phaseB(int k1, T (&re)[16], T (&im)[16], const bl_c2<T> *xc
  *   mid      = |X_128|^2 (meaningful in lane 0 only)
  * tw512: W512^k = exp(-2 pi i k/512), k = 0..255.
  */
-/* one pair: Z_k = (zr, zi), partner Z_(256-k) = (pr, pi), w = W512^k */
-template <typename T>
+/* one pair: Z_k = (zr, zi), partner Z_(256-k) = (pr, pi), w = W512^k.  QUARTER = false: the
+ * caller fed the transform x / 2, which already carries the 1/4 (an exact scaling). */
+template <typename T, bool QUARTER = true>
 BL_HD void bl_fft512_power1(T zr, T zi, T pr, T pi, bl_c2<T> w, T &own, T &mir) {
   const T er = zr + pr, ei = zi - pi;
   const T orr = zi + pi, oi = pr - zr;
@@ -168,8 +175,9 @@ BL_HD void bl_fft512_power1(T zr, T zi, T pr, T pi, bl_c2<T> w, T &own, T &mir) 
   const T tr = bl_fma(orr, w.re, -q);
   const T ti = bl_fma(orr, w.im, s);
   const T ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
-  own = (T)0.25 * bl_fma(ar, ar, ai * ai);
-  mir = (T)0.25 * bl_fma(br, br, bi * bi);
+  own = bl_fma(ar, ar, ai * ai);
+  mir = bl_fma(br, br, bi * bi);
+  if (QUARTER) { own = (T)0.25 * own; mir = (T)0.25 * mir; }
 }
 
 template <typename T>

@@ -185,7 +185,7 @@ __global__ void k_stats_init(bl_dstats *stats, int n_songs) {
   if (i >= n_songs) return;
   bl_dstats s;
   s.sum = 0; s.sumsq = 0; s.first = 0xFFFFFFFFu; s.last = -1;
-  s.mean = 0; s.variance = 0; s.vprime = 0; s.rcp = 0; s.wrap_pass = 0; s.status = BL_OK;
+  s.mean = 0; s.variance = 0; s.vprime = 0; s.rcp = 0; s.rcp_lo = 0; s.wrap_pass = 0; s.status = BL_OK;
   s.wrap_acc = 0;
   stats[i] = s;
 }
@@ -199,7 +199,11 @@ __device__ __forceinline__ void prep_finish(bl_dstats &s, int n) {
    *   = RN((s - mean) / (var * 2^-15)) exactly (power-of-two scalings commute
    *   with rounding); vprime and its reciprocal feed bl_norm() below. */
   s.vprime = (double)s.variance / 32768.0;
-  s.rcp = 1.0 / s.vprime;
+  /* The envelope kernel works on x / 2 (an exact scaling: see bl_norm), so the reciprocal is
+   * that of 2 * vprime, as an unevaluated sum rcp + rcp_lo accurate to ~2^-106. */
+  const double v2 = 2.0 * s.vprime;
+  s.rcp = 1.0 / v2;
+  s.rcp_lo = __builtin_fma(-s.rcp, v2, 1.0) / v2;
   (void)n;
 }
 
@@ -340,36 +344,53 @@ __global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__
 /* k_freq_frames                                                              */
 
 
-/* exchange buffers (the partner half rows and the per-wave power staging reuse them),
- * twiddles, Hann, the running spectrum and the relay word: 41.9 KB -> three workgroups per CU
- * (the kernel needs ~160 VGPRs) */
-#define BL_FREQ_ACC_OFF (16 * BL_FFT_XCH_ELEMS * 8 + 2 * 256 * 8 + 512 * 4)
-#define BL_FREQ_LDS_BYTES (BL_FREQ_ACC_OFF + 256 * 4 + 64)
-
 /*
- * One workgroup per song, its frames in order.  ref src/frequency_sort.c:88-93 adds every
- * frame's power spectrum into one f32 accumulator per bin, frame after frame; f32 addition
- * does not associate, so the order is part of the result (15 000 frames leave ~1e-5 of room
- * in `frequency`).  Each 16-lane group transforms one frame, a wave four consecutive frames
- * per iteration, the four waves 16; the running spectrum then goes round the waves like a
- * baton: wave w waits for the relay word to reach 4 * it + w, adds its four frames bin by bin
- * in frame order (its own power values re-laid out through its private exchange space: lane
- * j owns bins j, j + 64, j + 128, j + 192) and passes it on.  No workgroup barrier in the
- * loop; the waves stagger themselves by a quarter iteration.
+ * k_freq_frames: Hann window + 512-point f32 real DFT + per-bin power, summed over the frames in
+ * the reference's order (ref src/frequency_sort.c:67-94).
+ *
+ * One workgroup per song.  Every 16-lane group transforms TWO frames at once: all values are
+ * 2-vectors (frame A in .x, frame B in .y), so the whole transform is v_pk_add / v_pk_mul /
+ * v_pk_fma_f32 on register pairs with no shuffling between the halves — twice the f32 rate of
+ * the scalar VALU for the same instruction count (the one-frame-per-group kernel spent 40 % of
+ * its VALU stream on v_mov's that re-paired (re, im) for the packed instructions hipcc formed).
+ * A wave covers 8 consecutive frames per iteration, the four waves 32.
+ *
+ * ref :88-93 adds every frame's power spectrum into one f32 accumulator per bin, frame after
+ * frame; f32 addition does not associate, so the order is part of the result (15 000 frames
+ * leave ~1e-5 of room in `frequency`).  The running spectrum goes round the waves like a baton:
+ * wave w waits for the relay word to reach 4 * it + w, adds its eight frames bin by bin in frame
+ * order (its own power values re-laid out through its private exchange space: lane j owns bins
+ * j, j + 64, j + 128, j + 192) and passes it on.  No workgroup barrier in the loop; the waves
+ * stagger themselves by a quarter iteration.
+ *
+ * LDS: 16 exchange buffers of 272 (re, im) 2-vectors (16 bytes each: every exchange access is a
+ * b128), twiddles, Hann, the running spectrum, the relay word: 76.9 KB -> two workgroups per CU,
+ * two waves per SIMD (the kernel wants ~200 VGPRs: 64 for the data, 64 for the frames in flight).
  */
-__global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__ pcm,
-                                                     const bl_dsong *__restrict__ songs,
-                                                     bl_tables tb, float *spectrum) {
+typedef bl_c2<bl_f2> c2p; /* a complex number per frame of the pair */
+
+#define BL_FREQ_XCH_BYTES (16 * BL_FFT_XCH_ELEMS * 16)
+#define BL_FREQ_ACC_OFF (BL_FREQ_XCH_BYTES + 2 * 256 * 8 + 512 * 4)
+#define BL_FREQ_LDS_BYTES (BL_FREQ_ACC_OFF + 256 * 4 + 64)
+#define BL_FREQ_FPI 32 /* frames per workgroup iteration */
+/* row stride of the power staging: 2 rows = 16 banks (mod 32) apart, so the two 16-lane groups
+ * that share a 32-lane store group land on disjoint banks */
+#define BL_FREQ_SROW 264
+
+template <bool STEREO>
+__global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restrict__ pcm,
+                                                        const bl_dsong *__restrict__ songs,
+                                                        bl_tables tb, float *spectrum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  c2f *xch = reinterpret_cast<c2f *>(smem);                       /* 16 x 272 */
-  c2f *tw256 = xch + 16 * BL_FFT_XCH_ELEMS;
+  c2p *xch = reinterpret_cast<c2p *>(smem); /* 16 x 272 */
+  c2f *tw256 = reinterpret_cast<c2f *>(smem + BL_FREQ_XCH_BYTES);
   c2f *tw512 = tw256 + 256;
   float *hann = reinterpret_cast<float *>(tw512 + 256);
   float *accv = reinterpret_cast<float *>(smem + BL_FREQ_ACC_OFF); /* ps[0..255] so far */
   typedef __attribute__((address_space(3))) volatile int lds_vint;
   lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF + 256 * 4);
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-  const int wave = tid >> 6, lane = tid & 63, gl = g & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, gl = g & 3;
   const bl_dsong sg = songs[blockIdx.x];
   const int16_t *p = pcm + sg.pcm_off;
   tw256[tid] = tb.tw256_f[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
@@ -380,66 +401,125 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
   if (tid == 0) relay[0] = 0;
   __syncthreads();
 
-  c2f *gx = xch + g * BL_FFT_XCH_ELEMS, *gp = gx; /* partner rows alias the transpose */
-  float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [4][257] */
-  /* one frame ahead: 16 unconditional loads per lane (frame index clamped into the song,
-   * an inactive frame is zeroed when it is consumed), so the HBM latency of frame f+1
-   * hides behind the transform of frame f */
-  uint2 pre[16];
-  const bool stereo = sg.channels == 2;
+  c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* partner rows alias the transpose */
+  float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [8][BL_FREQ_SROW] */
+  /* one iteration ahead: 32 unconditional loads per lane (frame indices clamped into the song;
+   * a frame past the end is transformed like any other and simply not added), so the HBM
+   * latency of iteration it+1 hides behind the transforms of iteration it */
+  uint2 pa[16], pb[16];
+  constexpr bool stereo = STEREO; /* the batch is split by channel count on the host */
   auto fetch = [&](int f_) {
-    const int fc = min(f_, sg.n_frames - 1);
+    const int fa = min(f_, sg.n_frames - 1), fb = min(f_ + 1, sg.n_frames - 1);
     if (stereo) {
-      const uint2 *q = reinterpret_cast<const uint2 *>(p + (size_t)fc * 1024);
+      const uint2 *qa = reinterpret_cast<const uint2 *>(p + (size_t)fa * 1024);
+      const uint2 *qb = reinterpret_cast<const uint2 *>(p + (size_t)fb * 1024);
 #pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) pre[m1] = q[16 * m1 + l];
+      for (int m1 = 0; m1 < 16; ++m1) { pa[m1] = qa[16 * m1 + l]; pb[m1] = qb[16 * m1 + l]; }
     } else {
-      const unsigned *q = reinterpret_cast<const unsigned *>(p + (size_t)fc * 512);
+      const unsigned *qa = reinterpret_cast<const unsigned *>(p + (size_t)fa * 512);
+      const unsigned *qb = reinterpret_cast<const unsigned *>(p + (size_t)fb * 512);
 #pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) pre[m1] = make_uint2(q[16 * m1 + l], 0u);
+      for (int m1 = 0; m1 < 16; ++m1) {
+        pa[m1] = make_uint2(qa[16 * m1 + l], 0u);
+        pb[m1] = make_uint2(qb[16 * m1 + l], 0u);
+      }
     }
   };
-  const int n_iter = (sg.n_frames + 15) / 16;
-  fetch(g);
+  /* the two mono samples (one complex DFT input) a lane takes from an 8-byte (stereo) or 4-byte
+   * (mono) word, for both frames of the pair:
+   * stereo, ref :69-75: (float)((L + R) / 2), the integer average truncates towards zero —
+   * L + R converts exactly, half of it is exact, v_trunc does what the C division does;
+   * mono, ref :76-80: (float)s */
+  auto mono2 = [&](const uint2 wa, const uint2 wb, bl_f2 &s0, bl_f2 &s1) {
+    const int a0 = (int)(short)(wa.x & 0xFFFFu), a1 = (int)(short)(wa.x >> 16);
+    const int b0 = (int)(short)(wb.x & 0xFFFFu), b1 = (int)(short)(wb.x >> 16);
+    if (stereo) {
+      const int a2 = (int)(short)(wa.y & 0xFFFFu), a3 = (int)(short)(wa.y >> 16);
+      const int b2 = (int)(short)(wb.y & 0xFFFFu), b3 = (int)(short)(wb.y >> 16);
+      const bl_f2 h0 = (bl_f2){(float)(a0 + a1), (float)(b0 + b1)} * 0.5f;
+      const bl_f2 h1 = (bl_f2){(float)(a2 + a3), (float)(b2 + b3)} * 0.5f;
+      s0 = (bl_f2){__builtin_truncf(h0.x), __builtin_truncf(h0.y)};
+      s1 = (bl_f2){__builtin_truncf(h1.x), __builtin_truncf(h1.y)};
+    } else {
+      s0 = (bl_f2){(float)a0, (float)b0};
+      s1 = (bl_f2){(float)a1, (float)b1};
+    }
+  };
+  /* most of this lane's pass-1 twiddles W256^(l k1) stay in registers for the whole song (read
+   * from LDS inside the loop, each one put its latency in front of four dependent operations);
+   * the last three do come from LDS: with all 15 the kernel no longer fits 256 VGPRs */
+  constexpr int W1_REGS = 13;
+  c2f w1[W1_REGS];
+#pragma unroll
+  for (int k1 = 1; k1 < W1_REGS; ++k1) w1[k1] = tw256[k1 * 16 + l];
+  const int n_iter = (sg.n_frames + BL_FREQ_FPI - 1) / BL_FREQ_FPI;
+  fetch(8 * wave + 2 * gl);
   for (int it = 0; it < n_iter; ++it) {
-    const int f = it * 16 + g;
-    const bool active = f < sg.n_frames;
-    float re[16], im[16];
+    const int f = it * BL_FREQ_FPI + 8 * wave + 2 * gl;
+    bl_f2 re[16], im[16];
 #pragma unroll
     for (int m1 = 0; m1 < 16; ++m1) {
-      const uint2 w = pre[m1];
       const int d = 32 * m1 + 2 * l;
-      const int a0 = (int)(short)(w.x & 0xFFFFu), a1 = (int)(short)(w.x >> 16);
-      const int a2 = (int)(short)(w.y & 0xFFFFu), a3 = (int)(short)(w.y >> 16);
-      /* stereo, ref :69-75: (float)((L + R) / 2) * hann[d], the integer average truncates;
-       * mono, ref :76-80: (float)s * hann[d] */
-      const int s0 = stereo ? (a0 + a1) / 2 : a0;
-      const int s1 = stereo ? (a2 + a3) / 2 : a1;
-      re[m1] = active ? (float)s0 * hann[d] : 0.f;
-      im[m1] = active ? (float)s1 * hann[d + 1] : 0.f;
+      bl_f2 r, i;
+      mono2(pa[m1], pb[m1], r, i);
+      const bl_f2 h = *reinterpret_cast<const bl_f2 *>(hann + d); /* hann[d], hann[d + 1] */
+      re[m1] = r * (bl_f2){h.x, h.x};
+      im[m1] = i * (bl_f2){h.y, h.y};
     }
-    fetch(f + 16);
+    fetch(f + BL_FREQ_FPI);
     /* the exchange buffers of a 16-lane group are private to it, hence to its wave */
-    bl_fft512_phaseA<float>(l, re, im, tw256, gx);
+    bl_fft16(re, im);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const int ps = bl_pos16(k1);
+      bl_f2 r = re[ps], i = im[ps];
+      if (k1 != 0) {
+        const c2f w = k1 < W1_REGS ? w1[k1] : tw256[k1 * 16 + l];
+        bl_cmul(r, i, (bl_f2){w.re, w.re}, (bl_f2){w.im, w.im}); /* lane 0: w = 1 exactly */
+      }
+      c2p v; v.re = r; v.im = i;
+      gx[k1 * 17 + l] = v;
+    }
     bl_wave_sync();
-    bl_fft512_phaseB_load<float>(l, re, im, gx);
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) {
+      const c2p v = gx[l * 17 + n0];
+      re[n0] = v.re; im[n0] = v.im;
+    }
     bl_wave_sync();
-    bl_fft512_phaseB_publish<float>(l, re, im, gp);
+    bl_fft16(re, im);
+#pragma unroll
+    for (int k0 = 8; k0 < 16; ++k0) {
+      c2p v; v.re = re[bl_pos16(k0)]; v.im = im[bl_pos16(k0)];
+      gx[l * 9 + (k0 - 8)] = v; /* row stride 9: with 8, the eight lanes of a b128 store group share four banks */
+    }
     bl_wave_sync();
-    float own[8], mir[8], mid;
-    bl_fft512_phaseC<float>(l, re, im, tw512, gp, own, mir, mid);
+    bl_f2 own[8], mir[8];
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+      const int sl = bl_partner_slot(l, k0);
+      bl_f2 pr = re[bl_pos16(0)], pi = im[bl_pos16(0)];
+      if (sl >= 0) { const c2p v = gx[(sl >> 3) * 9 + (sl & 7)]; pr = v.re; pi = v.im; }
+      const c2f w = tw512[l + 16 * k0];
+      c2p wp; wp.re = (bl_f2){w.re, w.re}; wp.im = (bl_f2){w.im, w.im};
+      bl_fft512_power1<bl_f2>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, wp, own[k0], mir[k0]);
+    }
+    const bl_f2 mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
+    const bl_f2 mid = bl_fma(mr, mr, mi * mi);
     bl_wave_sync(); /* partner rows are consumed: the wave's exchange space becomes `stage` */
-    /* ref :88-93: re*re + im*im of bin d, for d = 1..255 (an inactive frame contributes +0) */
-    float *sg_ = stage + gl * 257;
+    /* ref :88-93: re*re + im*im of bin d, for d = 1..255 */
+    float *sa = stage + (2 * gl) * BL_FREQ_SROW, *sb = sa + BL_FREQ_SROW;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      sg_[l + 16 * k] = own[k];
-      sg_[256 - l - 16 * k] = mir[k];
+      sa[l + 16 * k] = own[k].x; sb[l + 16 * k] = own[k].y;
+      sa[256 - l - 16 * k] = mir[k].x; sb[256 - l - 16 * k] = mir[k].y;
     }
-    if (l == 0) sg_[128] = mid;
+    if (l == 0) { sa[128] = mid.x; sb[128] = mid.y; }
     bl_wave_sync();
-    /* the baton: frames 16 it + 4 w .. + 3 join the running spectrum after those of wave w - 1 */
+    /* the baton: frames 32 it + 8 w .. + 7 join the running spectrum after those of wave w - 1 */
     const int turn = 4 * it + wave;
+    /* frames beyond the song's last one (their loads were clamped onto it) are not added */
+    const int n_live = sg.n_frames - (it * BL_FREQ_FPI + 8 * wave);
     while (__builtin_amdgcn_readfirstlane(relay[0]) < turn) __builtin_amdgcn_s_sleep(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -447,7 +527,8 @@ __global__ __launch_bounds__(256) void k_freq_frames(const int16_t *__restrict__
       const int bin = lane + 64 * q;
       float acc = accv[bin];
 #pragma unroll
-      for (int fr = 0; fr < 4; ++fr) acc += stage[fr * 257 + bin];
+      for (int fr = 0; fr < 8; ++fr)
+        if (fr < n_live) acc += stage[fr * BL_FREQ_SROW + bin];
       accv[bin] = acc;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -496,22 +577,26 @@ __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ s
 /* ------------------------------------------------------------------------- */
 /* envelope windows: shared arithmetic                                        */
 
-/* ref tempo_atk_sort.c:109-114 for one sample: RN(((s/2^15) - (mean/2^15)) / vd).
- * k = s - mean is exact, q0 = k*rcp is within 2 ulp of k/vprime, the remainder
- * fma is exact and one correction lands on the correctly rounded quotient
- * (the distance of k/V from a rounding boundary is >= 2^-84 relative for
- * |k| < 2^17, V < 2^31, far above the 2^-105 error of the corrected value). */
-__device__ __forceinline__ double bl_norm(int k, double vprime, double rcp) {
+/* ref tempo_atk_sort.c:109-114 for one sample, halved: x/2 with x = RN(((s/2^15) - (mean/2^15)) / vd)
+ * = RN(k / V), k = s - mean (exact), V = variance * 2^-15 (power-of-two scalings commute with
+ * rounding).  With 1 / (2V) = r + r_lo to ~2^-106, kd*r + RN(kd*r_lo) is k / (2V) with a relative
+ * error below 2^-104 before the fma's single rounding; k / (2V) = k * 2^14 / variance with
+ * |k| < 2^17, variance < 2^31 is either exactly representable or at least 2^-70 (relative) away
+ * from the nearest rounding boundary, so the result is the correctly rounded quotient.
+ * Why halved: every operation downstream (add, multiply by a constant, fma) scales exactly by a
+ * power of two — nothing here comes near the subnormals — so the FIR outputs are y/2, the
+ * spectrum X/2 and the power terms |X|^2 / 4 with bit-identical mantissas: the 1/4 that the
+ * real-input split of the DFT owes (bl_fft512_power1) comes for free. */
+__device__ __forceinline__ double bl_norm(int k, double rcp, double rcp_lo) {
   const double kd = (double)k;
-  const double q0 = kd * rcp;
-  const double r0 = __builtin_fma(-q0, vprime, kd);
-  return __builtin_fma(r0, rcp, q0);
+  return __builtin_fma(kd, rcp, kd * rcp_lo);
 }
 
+/* ref :123-138.  The reference starts from y = 0 and adds nine products; 0 + c7 * p is c7 * p
+ * bit for bit here (p = +0 gives +0: the inputs are never -0), so the first add is not issued. */
 #define BL_FIR(X)                                                   \
   ({                                                                \
-    double y_ = 0;                                                  \
-    y_ += BL_C7 * (X(7) + X(9));                                    \
+    double y_ = BL_C7 * (X(7) + X(9));                              \
     y_ += BL_C6 * (X(6) + X(10));                                   \
     y_ += BL_C5 * (X(5) + X(11));                                   \
     y_ += BL_C4 * (X(4) + X(12));                                   \
@@ -665,7 +750,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
   /* ---- compute waves ---- */
   double *buf = reinterpret_cast<double *>(smem) + wave * EV2_SLOTS;
   const int mean = st.mean;
-  const double vprime = st.vprime, rcp = st.rcp;
+  const double rcp = st.rcp, rcp_lo = st.rcp_lo;
   /* lane ln owns samples 20*ln .. 20*ln+19 of the wave's 1280 (five 8-byte loads) plus
    * the one sample that starts its own zero-state output (lane (g, l): sample l of window
    * g); both are fetched one round ahead so that the HBM latency hides behind the
@@ -709,11 +794,11 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-          r[16 + 4 * u + 2 * k] = bl_norm(lo - mean, vprime, rcp);
-          r[16 + 4 * u + 2 * k + 1] = bl_norm(hi - mean, vprime, rcp);
+          r[16 + 4 * u + 2 * k] = bl_norm(lo - mean, rcp, rcp_lo);
+          r[16 + 4 * u + 2 * k + 1] = bl_norm(hi - mean, rcp, rcp_lo);
         }
       }
-      const double xh = bl_norm((int)preh - mean, vprime, rcp);
+      const double xh = bl_norm((int)preh - mean, rcp, rcp_lo);
       fetch(tile + gridDim.x); /* next round's samples */
 #pragma unroll
       for (int i = 0; i < 16; ++i) r[i] = bl_dpp_f64<0x138>(r[20 + i]); /* wave_shr:1 */
@@ -791,11 +876,12 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       const int sl = bl_partner_slot(l, k0);
       double pr = re[bl_pos16(0)], pi = im[bl_pos16(0)];
       if (sl >= 0) { const double2 v = pg[(sl >> 3) * 9 + (sl & 7)]; pr = v.x; pi = v.y; }
-      bl_fft512_power1<double>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
-                               own[k0], mir[k0]);
+      bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
+                                      own[k0], mir[k0]);
     }
+    /* |X_128|^2 = |Z_128|^2 has no 1/4 of its own: give back the one the halved input took */
     const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
-    const double mid = __builtin_fma(mr, mr, mi * mi);
+    const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
     while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
     ev2_lds_acquire();
     double *tg = terms + (4 * wave + g) * EV2_TROW;
@@ -1147,7 +1233,9 @@ int blk_configure_device(void) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   return BL_OK;
 }
@@ -1243,8 +1331,14 @@ int blk_analyze(const blk_analyze_args &a) {
   if (what & 2) {
     {
       Mark m(a.mark, a.mark_user, PK_FREQ, stream);
-      hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream, a.pcm,
-                         a.songs, a.tb, a.spectrum);
+      /* records are sorted stereo-first inside a launch group (blr fill_group): two launches,
+       * each with the channel handling compiled in */
+      if (a.n_stereo > 0)
+        hipLaunchKernelGGL(k_freq_frames<true>, dim3(a.n_stereo), dim3(256), BL_FREQ_LDS_BYTES, stream,
+                           a.pcm, a.songs, a.tb, a.spectrum);
+      if (a.n_stereo < n_songs)
+        hipLaunchKernelGGL(k_freq_frames<false>, dim3(n_songs - a.n_stereo), dim3(256), BL_FREQ_LDS_BYTES,
+                           stream, a.pcm, a.songs + a.n_stereo, a.tb, a.spectrum + (size_t)256 * a.n_stereo);
     }
     Mark m(a.mark, a.mark_user, PK_FREQ_FIN, stream);
     hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, a.spectrum, a.songs,

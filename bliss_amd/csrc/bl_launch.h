@@ -36,7 +36,8 @@ struct bl_dstats {
   int last;                 /* last index with a non-zero sample */
   int mean, variance;
   double vprime; /* variance * 2^-15 */
-  double rcp;    /* RN(1 / vprime) */
+  double rcp;    /* RN(1 / (2 vprime)) */
+  double rcp_lo; /* 1 / (2 vprime) - rcp, see bl_norm */
   int wrap_pass; /* 1: variance must come from k_variance_wrap */
   int status;
   long long wrap_acc; /* accumulator of k_variance_wrap */
@@ -77,6 +78,7 @@ struct blk_analyze_args {
   double *lc;                /* device scratch, one per envelope slot */
   bl_amd_song_result *results;
   int n_songs, max_n, what, n_cu, env_dbg;
+  int n_stereo;              /* records [0, n_stereo) are 2-channel songs, the rest mono */
   bl_tables tb;
   hipStream_t stream, side;  /* side == nullptr: envelope tail on `stream` */
   hipEvent_t ev_env, ev_tail;
