@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 #include "bl_runtime.h"
@@ -352,8 +353,18 @@ int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_de
 
 /* ---- host-memory batch: pinned staging, copy/compute overlap on 2 streams ---- */
 #ifndef BL_STAGE_THREADS
-#define BL_STAGE_THREADS 8 /* host threads of the staging copy */
+#define BL_STAGE_THREADS 8 /* host threads of the staging copy (BL_AMD_STAGE_THREADS overrides) */
 #endif
+
+static int stage_threads(void) {
+  static int n = 0;
+  if (!n) {
+    const char *e = getenv("BL_AMD_STAGE_THREADS");
+    n = e ? atoi(e) : BL_STAGE_THREADS;
+    n = n < 1 ? 1 : (n > 64 ? 64 : n);
+  }
+  return n;
+}
 
 static int host_mode(void) {
   int m = g_host_mode.load();
@@ -391,8 +402,11 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
   const size_t WAVE_BYTES = (size_t)2 << 30;
   int begin = 0, wave = 0;
   int rc = BL_OK;
-  /* the scratch workspace is per context, so the waves' kernels follow each other (event
-   * chain inside blr_analyze_device); the copies of wave w+1 overlap the kernels of wave w */
+  /* The scratch workspace is per context, so the waves' kernels follow each other (event chain
+   * inside blr_analyze_device); the copies of wave w+1 overlap the kernels of wave w.  The host
+   * only ever waits for a wave's TRANSFER (its pinned buffer is free again), never for its
+   * kernels: the device arena is reused in stream order.  Waiting for the kernels put the
+   * ~20 ms latency of the serial envelope tail between two transfers (44 instead of 55 GB/s). */
   hipEvent_t done[2] = {nullptr, nullptr};
   for (int k = 0; k < 2; ++k) BL_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
   bool used[2] = {false, false};
@@ -412,10 +426,14 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
       ++end;
     }
     const size_t bytes = elems * 2 + 64;
-    if (used[k]) { /* buffer k is free again once wave-2 has finished */
+    const bool trace = getenv("BL_AMD_HOST_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
+    if (used[k]) { /* pinned buffer k is free again once the transfer of wave-2 has finished */
       if (hipEventSynchronize(done[k]) != hipSuccess) { rc = BL_UNEXPECTED; break; }
       unregister_wave(c, k);
     }
+    const double t_b = now();
     if (blr_ensure(c->arena[k], bytes) != BL_OK) { rc = BL_UNEXPECTED; break; }
     hipStream_t s = c->streams[k];
     int16_t *d_arena = static_cast<int16_t *>(c->arena[k].p);
@@ -441,7 +459,7 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
       int16_t *stage = static_cast<int16_t *>(c->pinned[k]);
       /* staging copy on several host threads: one thread moves ~10 GB/s, the link takes more.
        * 32-bit sources are narrowed here (>> 16), so the link only ever carries s16. */
-      const int n_thr = (int)std::min<size_t>(BL_STAGE_THREADS, std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
+      const int n_thr = (int)std::min<size_t>((size_t)stage_threads(), std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
       auto copy_range = [&](int t) {
         for (size_t i = (size_t)t; i < desc.size(); i += (size_t)n_thr) {
           int16_t *dst = stage + desc[i].pcm_offset;
@@ -460,13 +478,15 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
       for (int t = 1; t < n_thr; ++t) pool.emplace_back(copy_range, t);
       copy_range(0);
       for (auto &th : pool) th.join();
+      if (trace) fprintf(stderr, "wave %d: wait %.1f ms, stage copy %.1f ms (%zu MB, %d threads)\n", wave,
+                         1e3 * (t_b - t_a), 1e3 * (now() - t_b), elems * 2 >> 20, n_thr);
       if (hipMemcpyAsync(d_arena, stage, elems * 2, hipMemcpyHostToDevice, s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
     }
+    if (hipEventRecord(done[k], s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
     if (blr_analyze_device(c, d_arena, desc.data(), (int)desc.size(), d_res + begin, s, 7) != BL_OK) {
       rc = BL_UNEXPECTED;
       break;
     }
-    if (hipEventRecord(done[k], s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
     used[k] = true;
     begin = end;
     ++wave;

@@ -12,8 +12,8 @@ for S in $STEPS; do
   case $S in
     tests) timeout 2400 python -m pytest tests -m gpu -x -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log;;
     bench) timeout 900 python bench.py > $OUT/bench_8192songs.json 2> $OUT/bench_8192songs.log; tail -c 600 $OUT/bench_8192songs.json;;
-    host)  timeout 600 python tools/host_path_bench.py --songs 512 --latency > $OUT/host_path_staged.json 2> $OUT/host_path_staged.log; cat $OUT/host_path_staged.json
-           timeout 600 python tools/host_path_bench.py --songs 512 --mode registered > $OUT/host_path_registered.json 2> $OUT/host_path_registered.log; cat $OUT/host_path_registered.json;;
+    host)  timeout 600 python tools/host_path_bench.py --songs 2048 --latency > $OUT/host_path_staged.json 2> $OUT/host_path_staged.log; cat $OUT/host_path_staged.json
+           timeout 600 python tools/host_path_bench.py --songs 1024 --mode registered > $OUT/host_path_registered.json 2> $OUT/host_path_registered.log; cat $OUT/host_path_registered.json;;
     mixed) timeout 600 python tools/mixed_bench.py > $OUT/mixed_8192songs.json 2> $OUT/mixed.log; cat $OUT/mixed_8192songs.json;;
   esac
 done
