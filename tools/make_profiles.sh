@@ -1,34 +1,35 @@
 #!/bin/bash
-# Regenerates the round's profile artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/prof/kernel_stats_1024songs.csv   rocprofv3 --kernel-trace --stats of bench.py (1024 songs)
-#   gpurun_out/prof/bench_1024songs_under_rocprof.json   the bench line of that same run
-#   gpurun_out/prof/hbm_traffic.json             FETCH_SIZE / WRITE_SIZE and SQ counters per kernel (256 songs,
-#                                                one --pmc pass per counter group, --kernel-trace only)
-#   gpurun_out/prof/bench_8192songs.json         the default bench line (outside the profiler)
-# usage: tools/make_profiles.sh [tag]
+# Regenerates a round's profile artefacts on the GPU box (run through gpurun from the repo root):
+#   kernel_stats_8192songs.csv          rocprofv3 --kernel-trace --stats of the default bench command
+#   bench_8192songs_under_rocprof.json  the bench line of that same run (HIP-event kernel times to compare)
+#   hbm_traffic.json                    FETCH_SIZE / WRITE_SIZE and SQ counters per kernel at 8192 songs
+#                                       (one --pmc pass per counter group, --kernel-trace only)
+#   bench_8192songs.json                the default bench line outside the profiler
+# usage: tools/make_profiles.sh [tag] [songs for the PMC passes]
 set -u
-TAG=${1:-final}
+TAG=${1:-r02}
+PSONGS=${2:-8192}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof
+OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B1024="python bench.py --songs-per-gpu 1024 --no-cpu-baseline"
-B256="python bench.py --songs-per-gpu 256 --steps 1 --warmup 0 --no-cpu-baseline"
-(cd $ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B1024 \
-   > $OUT/bench_1024songs_under_rocprof.json 2> $OUT/trace.log)
+BDEF="python bench.py --no-cpu-baseline"
+BPMC="python bench.py --songs-per-gpu $PSONGS --steps 1 --warmup 0 --no-cpu-baseline --verify 0"
+(cd $ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BDEF \
+   > $OUT/bench_8192songs_under_rocprof.json 2> $OUT/trace.log)
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- $B1024  (MI355X, $TAG)"; cat "$f"; } \
-   > $OUT/kernel_stats_1024songs.csv
+{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- $BDEF  (default workload: 8192 songs; MI355X, $TAG)"; cat "$f"; } \
+   > $OUT/kernel_stats_8192songs.csv
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
          "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
          "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
   i=$((i+1))
-  (cd $ROOT && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc$i -- $B256 \
+  (cd $ROOT && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc$i -- $BPMC \
      > $OUT/pmc$i.log 2>&1)
 done
-python $ROOT/tools/pmc_to_json.py $OUT "$B256" > $OUT/hbm_traffic.json
+python $ROOT/tools/pmc_to_json.py $OUT "$BPMC" $PSONGS > $OUT/hbm_traffic.json
 (cd $ROOT && timeout 900 python bench.py > $OUT/bench_8192songs.json 2> $OUT/bench_8192songs.log)
 rm -rf $OUT/trace $OUT/pmc[0-9]  # raw traces are large; the summaries above are what gets committed
 ls -la $OUT

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Folds the per-dispatch counter CSVs of tools/make_profiles.sh into one JSON: HBM bytes per kernel
 (FETCH_SIZE / WRITE_SIZE with the gfx950 corrections of MI355X_MICROARCH.md) and the SQ counters.
-usage: pmc_to_json.py <dir with pmc*/> "<profiled command>" """
+usage: pmc_to_json.py <dir with pmc*/> "<profiled command>" [songs in the profiled batch]"""
 import collections
 import csv
 import glob
@@ -12,7 +12,9 @@ SONGS = 256
 ALGO_BYTES_PER_SONG = 15876000 * 2  # 180 s x 44.1 kHz x 2 ch x s16
 
 
-def main(root, cmd):
+def main(root, cmd, songs=SONGS):
+    global SONGS
+    SONGS = int(songs)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in sorted(glob.glob(f"{root}/pmc*/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
@@ -48,4 +50,4 @@ def main(root, cmd):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
