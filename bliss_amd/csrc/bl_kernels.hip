@@ -378,9 +378,8 @@ typedef bl_c2<bl_f2> c2p; /* a complex number per frame of the pair */
 #define BL_FREQ_SROW 264
 
 template <bool STEREO>
-__global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restrict__ pcm,
-                                                        const bl_dsong *__restrict__ songs,
-                                                        bl_tables tb, float *spectrum) {
+__device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm, const bl_dsong &sg,
+                                                 const bl_tables &tb, float *spectrum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c2p *xch = reinterpret_cast<c2p *>(smem); /* 16 x 272 */
   c2f *tw256 = reinterpret_cast<c2f *>(smem + BL_FREQ_XCH_BYTES);
@@ -391,7 +390,6 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
   lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF + 256 * 4);
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, gl = g & 3;
-  const bl_dsong sg = songs[blockIdx.x];
   const int16_t *p = pcm + sg.pcm_off;
   tw256[tid] = tb.tw256_f[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
   tw512[tid] = tb.tw512_f[tid];
@@ -407,19 +405,22 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
    * a frame past the end is transformed like any other and simply not added), so the HBM
    * latency of iteration it+1 hides behind the transforms of iteration it */
   uint2 pa[16], pb[16];
-  constexpr bool stereo = STEREO; /* the batch is split by channel count on the host */
-  auto fetch = [&](int f_) {
+  constexpr bool stereo = STEREO; /* the channel handling is compiled in; k_freq_frames picks per workgroup */
+  /* loads of rows [4 * part, 4 * part + 4) of both frames: the iteration issues its 32 loads in
+   * four instalments between the phases of the transform (32 at once fill the vector-memory
+   * queue and the wave sits in front of it: 1.6 k cycles per iteration) */
+  auto fetch = [&](int f_, int part) {
     const int fa = min(f_, sg.n_frames - 1), fb = min(f_ + 1, sg.n_frames - 1);
     if (stereo) {
       const uint2 *qa = reinterpret_cast<const uint2 *>(p + (size_t)fa * 1024);
       const uint2 *qb = reinterpret_cast<const uint2 *>(p + (size_t)fb * 1024);
 #pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) { pa[m1] = qa[16 * m1 + l]; pb[m1] = qb[16 * m1 + l]; }
+      for (int m1 = 4 * part; m1 < 4 * part + 4; ++m1) { pa[m1] = qa[16 * m1 + l]; pb[m1] = qb[16 * m1 + l]; }
     } else {
       const unsigned *qa = reinterpret_cast<const unsigned *>(p + (size_t)fa * 512);
       const unsigned *qb = reinterpret_cast<const unsigned *>(p + (size_t)fb * 512);
 #pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) {
+      for (int m1 = 4 * part; m1 < 4 * part + 4; ++m1) {
         pa[m1] = make_uint2(qa[16 * m1 + l], 0u);
         pb[m1] = make_uint2(qb[16 * m1 + l], 0u);
       }
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
 #pragma unroll
   for (int k1 = 1; k1 < W1_REGS; ++k1) w1[k1] = tw256[k1 * 16 + l];
   const int n_iter = (sg.n_frames + BL_FREQ_FPI - 1) / BL_FREQ_FPI;
-  fetch(8 * wave + 2 * gl);
+#pragma unroll
+  for (int part = 0; part < 4; ++part) fetch(8 * wave + 2 * gl, part);
   for (int it = 0; it < n_iter; ++it) {
     const int f = it * BL_FREQ_FPI + 8 * wave + 2 * gl;
     bl_f2 re[16], im[16];
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
       re[m1] = r * (bl_f2){h.x, h.x};
       im[m1] = i * (bl_f2){h.y, h.y};
     }
-    fetch(f + BL_FREQ_FPI);
+    fetch(f + BL_FREQ_FPI, 0);
     /* the exchange buffers of a 16-lane group are private to it, hence to its wave */
     bl_fft16(re, im);
 #pragma unroll
@@ -481,12 +483,14 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
       gx[k1 * 17 + l] = v;
     }
     bl_wave_sync();
+    fetch(f + BL_FREQ_FPI, 1);
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) {
       const c2p v = gx[l * 17 + n0];
       re[n0] = v.re; im[n0] = v.im;
     }
     bl_wave_sync();
+    fetch(f + BL_FREQ_FPI, 2);
     bl_fft16(re, im);
 #pragma unroll
     for (int k0 = 8; k0 < 16; ++k0) {
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
       gx[l * 9 + (k0 - 8)] = v; /* row stride 9: with 8, the eight lanes of a b128 store group share four banks */
     }
     bl_wave_sync();
+    fetch(f + BL_FREQ_FPI, 3);
     bl_f2 own[8], mir[8];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
@@ -520,23 +525,45 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
     const int turn = 4 * it + wave;
     /* frames beyond the song's last one (their loads were clamped onto it) are not added */
     const int n_live = sg.n_frames - (it * BL_FREQ_FPI + 8 * wave);
+    /* this wave's 8 x 4 power values per lane are fetched BEFORE it asks for the baton (they are
+     * its own), all 32 reads in flight at once; holding the baton then costs one read of the
+     * running spectrum, eight dependent adds and a write.  (Reading them one by one behind the
+     * frame-count test made the hold 3.2 k cycles: four waves x 3.2 k was the whole iteration.) */
+    float sv[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int fr = 0; fr < 8; ++fr) sv[q][fr] = stage[fr * BL_FREQ_SROW + lane + 64 * q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     while (__builtin_amdgcn_readfirstlane(relay[0]) < turn) __builtin_amdgcn_s_sleep(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int bin = lane + 64 * q;
-      float acc = accv[bin];
+    for (int q = 0; q < 4; ++q) acc[q] = accv[lane + 64 * q];
 #pragma unroll
-      for (int fr = 0; fr < 8; ++fr)
-        if (fr < n_live) acc += stage[fr * BL_FREQ_SROW + bin];
-      accv[bin] = acc;
-    }
+    for (int fr = 0; fr < 8; ++fr)
+      if (fr < n_live) { /* wave-uniform */
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += sv[q][fr];
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accv[lane + 64 * q] = acc[q];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bl_wave_sync();
     if (lane == 0) relay[0] = turn + 1;
   }
   __syncthreads();
   spectrum[(size_t)blockIdx.x * 256 + tid] = accv[tid];
+}
+
+/* one workgroup per song; the channel count is uniform per workgroup, so the branch costs one
+ * scalar compare and each path keeps its compiled-in input side */
+__global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restrict__ pcm,
+                                                        const bl_dsong *__restrict__ songs,
+                                                        bl_tables tb, float *spectrum) {
+  const bl_dsong sg = songs[blockIdx.x];
+  if (sg.channels == 2) freq_frames_body<true>(pcm, sg, tb, spectrum);
+  else freq_frames_body<false>(pcm, sg, tb, spectrum);
 }
 
 __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ spectrum,
@@ -933,11 +960,10 @@ __global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ s
   if (valid) sg = songs[song];
   else { sg.nb_frames = 0; sg.n_windows = 0; sg.env_off = 0; sg.n = 1; sg.duration = 1; }
   const int N = 2 * sg.nb_frames;
-  int maxN = N, minN = valid ? N : 0x7fffffff;
+  int maxN = N;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     maxN = max(maxN, __shfl_xor(maxN, off));
-    minN = min(minN, __shfl_xor(minN, off));
   }
   if (threadIdx.x < 2) flags[threadIdx.x] = 0;
   __syncthreads();
@@ -995,10 +1021,15 @@ __global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ s
     ev2_lds_acquire();
     const double *yin = yblk[kb & 1] + lane;
     const int j = 38 * kb;
-    /* wave-uniform: every song of the wave is in its steady state for the whole block */
-    if (bl_tail_post::chunk_ok(j, minN)) {
+    /* A song in its steady state for the whole block takes the straight-line path; the others —
+     * the first 40 steps (the same block for every song) and each song's own last dozen — take
+     * the step-by-step one.  With equal lengths the branch is wave-uniform.  With mixed lengths
+     * both sides run for the one or two blocks in which a song of the wave ends (exec-masked),
+     * instead of the whole wave falling back for every block after its shortest song: that
+     * fallback was 6 % of the longest song's blocks at ~10 x the cost. */
+    if (bl_tail_post::chunk_ok(j, N)) {
       t.fast_chunk38(yin, 64);
-    } else {
+    } else if (j < N) {
       for (int q = 0; q < 38; ++q) {
         const int jj = j + q;
         if (jj < N) {
@@ -1233,9 +1264,7 @@ int blk_configure_device(void) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames<false>),
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   return BL_OK;
 }
@@ -1331,14 +1360,8 @@ int blk_analyze(const blk_analyze_args &a) {
   if (what & 2) {
     {
       Mark m(a.mark, a.mark_user, PK_FREQ, stream);
-      /* records are sorted stereo-first inside a launch group (blr fill_group): two launches,
-       * each with the channel handling compiled in */
-      if (a.n_stereo > 0)
-        hipLaunchKernelGGL(k_freq_frames<true>, dim3(a.n_stereo), dim3(256), BL_FREQ_LDS_BYTES, stream,
-                           a.pcm, a.songs, a.tb, a.spectrum);
-      if (a.n_stereo < n_songs)
-        hipLaunchKernelGGL(k_freq_frames<false>, dim3(n_songs - a.n_stereo), dim3(256), BL_FREQ_LDS_BYTES,
-                           stream, a.pcm, a.songs + a.n_stereo, a.tb, a.spectrum + (size_t)256 * a.n_stereo);
+      hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream, a.pcm,
+                         a.songs, a.tb, a.spectrum);
     }
     Mark m(a.mark, a.mark_user, PK_FREQ_FIN, stream);
     hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, a.spectrum, a.songs,

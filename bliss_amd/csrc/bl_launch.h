@@ -78,7 +78,6 @@ struct blk_analyze_args {
   double *lc;                /* device scratch, one per envelope slot */
   bl_amd_song_result *results;
   int n_songs, max_n, what, n_cu, env_dbg;
-  int n_stereo;              /* records [0, n_stereo) are 2-channel songs, the rest mono */
   bl_tables tb;
   hipStream_t stream, side;  /* side == nullptr: envelope tail on `stream` */
   hipEvent_t ev_env, ev_tail;

@@ -212,7 +212,7 @@ int validate_desc(const bl_amd_song_desc &d, int i) {
 /* host mirror of the per-song geometry (integer work of ref tempo_atk_sort.c:63-67,
  * frequency_sort.c:50) for one launch group, written to `out` (pinned) */
 void fill_group(const bl_amd_song_desc *desc, int n_songs, bl_dsong *out, long long &env_total,
-                int &max_n, int &n_stereo) {
+                int &max_n) {
   env_total = 0;
   max_n = 0;
   for (int i = 0; i < n_songs; ++i) {
@@ -238,17 +238,9 @@ void fill_group(const bl_amd_song_desc *desc, int n_songs, bl_dsong *out, long l
    * Results go back to the caller's order through out_idx; scratch offsets keep the
    * caller's order too.  Equal lengths: the order is left alone. */
   bool mixed = false;
-  n_stereo = 0;
-  for (int i = 0; i < n_songs; ++i) {
-    mixed = mixed || out[i].n != out[0].n || out[i].channels != out[0].channels;
-    n_stereo += out[i].channels == 2;
-  }
-  /* stereo records first (the frequency kernel is compiled per channel count), longest first
-   * within each kind */
+  for (int i = 1; i < n_songs && !mixed; ++i) mixed = out[i].n != out[0].n;
   if (mixed)
-    std::stable_sort(out, out + n_songs, [](const bl_dsong &a, const bl_dsong &b) {
-      return a.channels != b.channels ? a.channels > b.channels : a.n > b.n;
-    });
+    std::stable_sort(out, out + n_songs, [](const bl_dsong &a, const bl_dsong &b) { return a.n > b.n; });
 }
 
 } // namespace
@@ -297,11 +289,11 @@ int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_de
   if (ring_get(c, sizeof(bl_dsong) * (size_t)n_songs, &slot) != BL_OK) return BL_UNEXPECTED;
   bl_dsong *hs = static_cast<bl_dsong *>(slot->p);
   std::vector<long long> env_total(n_groups);
-  std::vector<int> max_n(n_groups), n_stereo(n_groups);
+  std::vector<int> max_n(n_groups);
   long long env_max = 0;
   for (int gi = 0; gi < n_groups; ++gi) {
     const int b = gi * G, cnt = std::min(G, n_songs - b);
-    fill_group(h_desc + b, cnt, hs + b, env_total[gi], max_n[gi], n_stereo[gi]);
+    fill_group(h_desc + b, cnt, hs + b, env_total[gi], max_n[gi]);
     env_max = std::max(env_max, env_total[gi]);
   }
   const int gmax = std::min(G, n_songs);
@@ -332,7 +324,6 @@ int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_de
     a.results = d_results + b;
     a.n_songs = cnt;
     a.max_n = max_n[gi];
-    a.n_stereo = n_stereo[gi];
     a.what = what;
     a.n_cu = c->n_cu;
     a.env_dbg = c->env_dbg;
@@ -620,8 +611,7 @@ int bl_amd_synth_pcm_device(int16_t *d_pcm, const bl_amd_song_desc *h_desc, int 
   std::vector<int> max_n((n_songs + G - 1) / G);
   for (int b = 0, gi = 0; b < n_songs; b += G, ++gi) {
     long long env_total;
-    int n_stereo;
-    fill_group(h_desc + b, std::min(G, n_songs - b), hs + b, env_total, max_n[gi], n_stereo);
+    fill_group(h_desc + b, std::min(G, n_songs - b), hs + b, env_total, max_n[gi]);
   }
   bl_dsong *d_songs = static_cast<bl_dsong *>(c->songs.p);
   BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs, sizeof(bl_dsong) * (size_t)n_songs, hipMemcpyHostToDevice, s));

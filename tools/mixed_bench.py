@@ -32,17 +32,27 @@ def main():
     torch.cuda.synchronize()
     corpus.analyze()
     torch.cuda.synchronize()
+    lib = bliss_amd.load()
+    lib.bl_amd_profile_reset(); lib.bl_amd_profile(1)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         corpus.analyze()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    lib.bl_amd_profile(0)
+    import ctypes as C
+    kern = {}
+    for name in ("pcm_scan", "amp_finish", "freq_frames", "env_windows", "env_tail"):
+        n = C.c_int(0)
+        ms = lib.bl_amd_profile_ms(name.encode(), C.byref(n))
+        kern[name] = round(ms / max(n.value, 1), 2)
     res = corpus.fetch()
     gb = corpus.pcm_bytes / 1e9
     print(json.dumps({"songs": a.songs, "pcm_GB": round(gb, 1), "mean_seconds": round(float(secs.mean()), 1),
                       "ms_per_batch": round(dt * 1e3, 1), "songs_per_s": round(a.songs / dt, 1),
                       "pcm_GB_per_s": round(gb / dt, 1),
                       "equivalent_S180_songs_per_s": round(gb * 1e9 / 31752000 / dt, 1),
+                      "kernels_ms_per_batch": kern,
                       "status_ok": bool(np.all(res["status"] == 0))}))
 
 
