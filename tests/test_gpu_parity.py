@@ -321,7 +321,8 @@ def test_extreme_amplitudes(gpu_lib, oracle):
 
 def test_random_soak_small(gpu_lib, oracle):
     """tools/soak.py on 24 random songs (random rate / channels / level / spectrum / DC / silences): integers
-    exact, floats within 1e-5 + 1e-4 |ref| (ref tests/test_analyze.c:30-35 uses 1e-5 absolute)."""
+    exact; tempo / amplitude / attack within 1e-4 relative (tempo and amplitude bit-identical); frequency and
+    force within 1e-5 + 1e-4 |ref| (ref tests/test_analyze.c:30-35 uses 1e-5 absolute)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
     import soak
@@ -338,7 +339,13 @@ def test_random_soak_small(gpu_lib, oracle):
             assert int(got[i][k]) == int(ref[k]), (i, k, int(got[i][k]), int(ref[k]))
         for k in FLOATS:
             a, b = float(got[i][k]), float(ref[k])
-            assert abs(a - b) <= 1e-5 + REL * abs(b), (i, k, a, b)
+            # frequency (and force, which contains it) is a difference of O(10) terms that crosses zero and
+            # goes through an f32 DFT that is not the oracle's: the reference's own absolute 1e-5 applies;
+            # the exactly-ordered parts of the path are held to the strict relative bound
+            tol = 1e-5 + REL * abs(b) if k in ("frequency", "force") else REL * max(abs(b), 1e-6)
+            assert abs(a - b) <= tol, (i, k, a, b)
+        assert np.float32(got[i]["tempo"]) == np.float32(ref["tempo"])
+        assert np.float32(got[i]["amplitude"]) == np.float32(ref["amplitude"])
 
 
 def test_invalid_inputs_are_rejected(gpu_lib, tmp_path):

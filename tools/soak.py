@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Randomised parity soak: N random songs (length, channels, level, spectrum, DC, silences) through the
-HIP batch path and through the CPU oracle (one process per host core), integers compared exactly and
-floats with |x - y| <= 1e-5 + 1e-4 |y| (north-star relative tolerance plus the absolute 1e-5 of the
-reference's own test, ref tests/test_analyze.c:30-35: frequency and force are differences of
-O(10) quantities and cross zero); prints a JSON summary.  Test infrastructure (uses oracle/).
+HIP batch path and through the CPU oracle (one process per host core), integers compared exactly,
+tempo / amplitude / attack to 1e-4 relative (north-star) and frequency / force with
+|x - y| <= 1e-5 + 1e-4 |y| (plus the absolute 1e-5 of the reference's own test, ref
+tests/test_analyze.c:30-35: they are differences of O(10) quantities and cross zero); prints a JSON
+summary.  Test infrastructure (uses oracle/).
 usage: python tools/soak.py [--songs 512] [--seed 1] [--max-seconds 40]"""
 import argparse
 import json
@@ -105,7 +106,10 @@ def main():
             x, y = float(g[k]), float(r[k])
             worst = max(worst, abs(x - y))
             worst_by[k] = max(worst_by[k], abs(x - y))
-            if abs(x - y) > 1e-5 + 1e-4 * abs(y):
+            # frequency / force: the reference's own absolute 1e-5 on top of the relative bound (they
+            # cross zero and go through an f32 DFT that is not the oracle's); the rest: strict relative
+            tol = 1e-5 + 1e-4 * abs(y) if k in ("frequency", "force") else 1e-4 * max(abs(y), 1e-6)
+            if abs(x - y) > tol:
                 bad_float.append((s, k, x, y))
             if np.float32(x) != np.float32(y):
                 not_bitwise += 1
@@ -115,7 +119,8 @@ def main():
                       "n_float_out_of_tolerance": len(bad_float), "float_fields_not_bit_identical": not_bitwise,
                       "worst_abs_err": worst, "worst_abs_err_by_field": worst_by, "not_bit_identical_by_field": nbit_by, "min_peak_margin": min_margin,
                       "gpu_seconds_incl_synthesis_and_upload": round(t1 - t0, 2),
-                      "oracle_seconds": round(t2 - t1, 2), "procs": a.procs or os.cpu_count()}))
+                      "oracle_seconds": round(t2 - t1, 2), "procs": a.procs or os.cpu_count(),
+                      "tolerance": "ints exact; tempo/amplitude/attack 1e-4 rel; frequency/force 1e-5 + 1e-4 |ref|"}))
     return 1 if (bad_int or bad_float) else 0
 
 
