@@ -974,28 +974,31 @@ __global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ s
     bl_tail_iir a;
     a.init();
     const double *mine = tile + lane * (BL_TAIL_TW + 1);
+    /* The next tile of the compressed envelope (BL_TAIL_TW windows x 64 songs) is fetched into
+     * registers while the recurrence runs over the current one, and only transposed into LDS when
+     * it is due: fetched on demand, the 64 loads of a tile (16 in flight) put ~18 k cycles of HBM
+     * latency in front of every third block — more than the recurrence itself. */
+    double pv[64];
+    auto issue = [&](int kb_) {
+      const int w = 19 * kb_ + lane;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int nw = __shfl(sg.n_windows, i);
+        const long long off = __shfl(sg.env_off, i);
+        pv[i] = (lane < BL_TAIL_TW && w < nw) ? lc[off + w] : 0.0;
+      }
+    };
+    issue(0);
     for (int kb = 0; kb < n_blocks; ++kb) {
       const int sub = kb % 3;
       if (sub == 0) {
-        /* stage BL_TAIL_TW windows x 64 songs of the compressed envelope, transposed;
-         * 16 independent loads in flight per lane */
-        const int wbase = 19 * kb;
         bl_wave_sync();
-        for (int sb = 0; sb < 64; sb += 16) {
-          double v[16];
+        if (lane < BL_TAIL_TW) {
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int nw = __shfl(sg.n_windows, sb + u);
-            const long long off = __shfl(sg.env_off, sb + u);
-            const int w = wbase + lane;
-            v[u] = (lane < BL_TAIL_TW && w < nw) ? lc[off + w] : 0.0;
-          }
-          if (lane < BL_TAIL_TW) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) tile[(sb + u) * (BL_TAIL_TW + 1) + lane] = v[u];
-          }
+          for (int i = 0; i < 64; ++i) tile[i * (BL_TAIL_TW + 1) + lane] = pv[i];
         }
         bl_wave_sync();
+        issue(kb + 3);
       }
       double *yo = yblk[kb & 1] + lane;
       double ye[38];

@@ -171,3 +171,41 @@ def test_malformed_vorbis_comment_lengths(lib, tmp_path):
     write_flac_verbatim(p, s16, 2, 22050, 16, comment_block=good)
     rc, _, meta = _decode(lib, p)
     assert rc == _lib.BL_OK and meta["title"] == b"Hey"
+
+
+def test_decoder_survives_corrupted_files(lib, tmp_path):
+    """Byte flips, truncations and garbage tails of a real FLAC and of a WAV: bl_audio_decode may
+    fail or succeed, but it returns (no crash, no hang) and leaves a struct that bl_free_song
+    accepts."""
+    rng = np.random.default_rng(77)
+    flac = bytearray(open(os.path.join(GOLD, "song.flac"), "rb").read())
+    wav_pcm = rng.integers(-3000, 3000, 2 * 6000).astype(np.int16)
+    wav = bytearray(b"RIFF" + struct.pack("<I", 36 + wav_pcm.nbytes) + b"WAVE" + b"fmt " +
+                    struct.pack("<IHHIIHH", 16, 1, 2, 22050, 22050 * 4, 4, 16) + b"data" +
+                    struct.pack("<I", wav_pcm.nbytes) + wav_pcm.tobytes())
+    ok = 0
+    for trial in range(120):
+        src = flac if trial % 3 else wav
+        data = bytearray(src)
+        kind = trial % 4
+        if kind == 0:      # flips in the header / metadata region
+            for _ in range(8):
+                data[int(rng.integers(0, min(len(data), 9000)))] ^= int(rng.integers(1, 256))
+        elif kind == 1:    # flips anywhere
+            for _ in range(40):
+                data[int(rng.integers(0, len(data)))] ^= int(rng.integers(1, 256))
+        elif kind == 2:    # truncation
+            data = data[: int(rng.integers(5, len(data)))]
+        else:              # a length field blown up
+            pos = int(rng.integers(4, 60))
+            data[pos:pos + 4] = b"\xff\xff\xff\x7f"
+        p = tmp_path / f"c{trial}.bin"
+        p.write_bytes(bytes(data))
+        song = _lib.BlSong()
+        rc = lib.bl_audio_decode(str(p).encode(), C.byref(song))
+        assert rc in (_lib.BL_OK, _lib.BL_UNEXPECTED)
+        if rc == _lib.BL_OK:
+            ok += 1
+            assert song.nSamples > 0 and song.channels in (1, 2) and song.sample_array
+            lib.bl_free_song(C.byref(song))
+    assert ok > 0
