@@ -931,29 +931,37 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_env_tail: one lane per song, two waves per 64 songs                      */
+/* k_env_tail: one lane per song, three waves per 64 songs                    */
 /*
  * Parts 2-3 of bl_envelope_sort are serial per song.  The 6th-order recurrence is a chain
  * of 8 dependent f64 operations per step, everything after y_j (onset difference, weighted
- * average, two box filters, peak test) another ~30; one wave issuing both in order needs
- * ~340 cycles per step.  Here wave 0 of the workgroup runs the recurrence (bl_tail_iir) and
- * hands y_j to wave 1 (bl_tail_post) through a double-buffered LDS block of 38 steps x 64
- * songs; the two overlap and a step costs what the slower stage costs.
+ * average, two box filters, peak test) another ~30; one wave issuing all of it in order needs
+ * ~340 cycles per step.  Three waves of the workgroup share it as a pipeline over 38-step blocks
+ * of 64 songs:
+ *   wave 0  the recurrence (bl_tail_iir)                        -> y_j   (yblk, double-buffered)
+ *   wave 1  onset weighting, atk, first box filter (bl_tail_ab)  -> o1    (oblk + per-lane counts)
+ *   wave 2  second box filter, peak test (bl_tail_c)             -> beat
+ * Every wave sits alone on a SIMD and is bound by its own dependent chain; a step costs what the
+ * slowest stage costs — the recurrence, ~90 cycles.  The o1 stream is not one value per step at
+ * the edges of a song (bl_box19): a block carries up to 48 values per lane and a count.
  */
-#define BL_TAIL_TW 57 /* windows per staged input tile: 114 steps = three 38-step blocks */
+#define BL_TAIL_OMAX 48 /* 38 + the 10 values box 1 flushes when a song ends */
 
-__global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ songs,
+__global__ __launch_bounds__(192) void k_env_tail(const bl_dsong *__restrict__ songs,
                                                   const double *__restrict__ lc, int n_songs,
                                                   bl_amd_song_result *res, int what) {
-  __shared__ double tile[64 * (BL_TAIL_TW + 1)]; /* wave 0: compressed envelope, transposed */
   __shared__ double yblk[2][38 * 64];            /* y_j of one block, [step][song] */
-  __shared__ double rings[48 * 64];              /* wave 1: box-filter rings */
-  __shared__ int flag_mem[2];
+  __shared__ double oblk[2][BL_TAIL_OMAX * 64];  /* box-1 outputs of one block, [slot][song] */
+  __shared__ int ocnt[2][64];                    /* how many of them per song */
+  __shared__ double rings_ab[29 * 64];           /* wave 1: box-1 ring + its 10 `old` cells */
+  __shared__ double rings_c[19 * 64];            /* wave 2: box-2 ring */
+  __shared__ int flag_mem[4];
   typedef __attribute__((address_space(3))) volatile int lds_vint;
-  lds_vint *flags = (lds_vint *)flag_mem; /* [0]: blocks produced, [1]: blocks consumed */
+  /* [0]: y blocks produced, [1]: y blocks consumed, [2]: o1 blocks produced, [3]: o1 blocks consumed */
+  lds_vint *flags = (lds_vint *)flag_mem;
   /* a handful of latency-bound waves that run beside the wide kernels: let them issue first */
   __builtin_amdgcn_s_setprio(3);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int song = blockIdx.x * 64 + lane;
   const bool valid = song < n_songs;
   bl_dsong sg;
@@ -962,10 +970,8 @@ __global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ s
   const int N = 2 * sg.nb_frames;
   int maxN = N;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    maxN = max(maxN, __shfl_xor(maxN, off));
-  }
-  if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+  for (int off = 32; off > 0; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
+  if (threadIdx.x < 4) flags[threadIdx.x] = 0;
   __syncthreads();
   const int n_blocks = (maxN + 37) / 38;
 
@@ -973,37 +979,27 @@ __global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ s
     /* ---- the recurrence: input pairs (x_j, 0) -> (y_j, y_j+1) ---- */
     bl_tail_iir a;
     a.init();
-    const double *mine = tile + lane * (BL_TAIL_TW + 1);
-    /* The next tile of the compressed envelope (BL_TAIL_TW windows x 64 songs) is fetched into
-     * registers while the recurrence runs over the current one, and only transposed into LDS when
-     * it is due: fetched on demand, the 64 loads of a tile (16 in flight) put ~18 k cycles of HBM
-     * latency in front of every third block — more than the recurrence itself. */
-    double pv[64];
-    auto issue = [&](int kb_) {
-      const int w = 19 * kb_ + lane;
+    /* Every lane reads its own song's compressed envelope, 19 windows (one block) at a time and
+     * two blocks ahead, straight into registers: three register sets rotate through "in use",
+     * "arriving" and "being requested".  The loads are unconditional from clamped addresses
+     * (under an exec mask hipcc waits vmcnt(0) after every few of them) and a window past the
+     * song's end is zeroed where it is used.  Earlier forms: one coalesced load per song and a
+     * transposition through LDS, fetched on demand (~18 k cycles of HBM latency in front of every
+     * third block, more than the recurrence itself) or a tile ahead (the 64 x 3 v_readlane that
+     * fetch song i's geometry still cost 9 k cycles per tile). */
+    const double *mylc = lc + sg.env_off;
+    const int nw = sg.n_windows;
+    auto fetch = [&](int kb_, double (&dst)[19]) {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) {
-        const int nw = __shfl(sg.n_windows, i);
-        const long long off = __shfl(sg.env_off, i);
-        pv[i] = (lane < BL_TAIL_TW && w < nw) ? lc[off + w] : 0.0;
-      }
+      for (int q = 0; q < 19; ++q) dst[q] = mylc[max(min(19 * kb_ + q, nw - 1), 0)];
     };
-    issue(0);
-    for (int kb = 0; kb < n_blocks; ++kb) {
-      const int sub = kb % 3;
-      if (sub == 0) {
-        bl_wave_sync();
-        if (lane < BL_TAIL_TW) {
-#pragma unroll
-          for (int i = 0; i < 64; ++i) tile[i * (BL_TAIL_TW + 1) + lane] = pv[i];
-        }
-        bl_wave_sync();
-        issue(kb + 3);
-      }
+    auto block = [&](int kb, double (&cur)[19], double (&fut)[19]) {
+      if (kb >= n_blocks) return;
+      fetch(kb + 2, fut);
       double *yo = yblk[kb & 1] + lane;
       double ye[38];
 #pragma unroll
-      for (int q = 0; q < 19; ++q) a.pair(mine[19 * sub + q], ye[2 * q], ye[2 * q + 1]);
+      for (int q = 0; q < 19; ++q) a.pair(19 * kb + q < nw ? cur[q] : 0.0, ye[2 * q], ye[2 * q + 1]);
       /* the buffer is free once the block before the previous one has been consumed */
       while (__builtin_amdgcn_readfirstlane(flags[1]) < kb - 1) __builtin_amdgcn_s_sleep(1);
       ev2_lds_acquire();
@@ -1012,45 +1008,84 @@ __global__ __launch_bounds__(128) void k_env_tail(const bl_dsong *__restrict__ s
       ev2_lds_release();
       bl_wave_sync();
       if (lane == 0) flags[0] = kb + 1;
+    };
+    double pa[19], pb[19], pc[19];
+    fetch(0, pa);
+    fetch(1, pb);
+    for (int kb = 0; kb < n_blocks; kb += 3) {
+      block(kb, pa, pc);
+      block(kb + 1, pb, pa);
+      block(kb + 2, pc, pb);
     }
     return;
   }
 
-  /* ---- everything after y_j ---- */
-  bl_tail_post t;
-  t.init(sg.nb_frames, rings + lane, 64);
-  for (int kb = 0; kb < n_blocks; ++kb) {
-    while (__builtin_amdgcn_readfirstlane(flags[0]) < kb + 1) __builtin_amdgcn_s_sleep(1);
-    ev2_lds_acquire();
-    const double *yin = yblk[kb & 1] + lane;
-    const int j = 38 * kb;
-    /* A song in its steady state for the whole block takes the straight-line path; the others —
-     * the first 40 steps (the same block for every song) and each song's own last dozen — take
-     * the step-by-step one.  With equal lengths the branch is wave-uniform.  With mixed lengths
-     * both sides run for the one or two blocks in which a song of the wave ends (exec-masked),
-     * instead of the whole wave falling back for every block after its shortest song: that
-     * fallback was 6 % of the longest song's blocks at ~10 x the cost. */
-    if (bl_tail_post::chunk_ok(j, N)) {
-      t.fast_chunk38(yin, 64);
-    } else if (j < N) {
-      for (int q = 0; q < 38; ++q) {
-        const int jj = j + q;
-        if (jj < N) {
-          t.step(jj, yin[q * 64]);
-          if (jj == N - 1) t.finish();
+  if (wave == 1) {
+    /* ---- y_j -> weighting, atk, box 1 -> o1 ---- */
+    bl_tail_ab t;
+    t.init(sg.nb_frames, rings_ab + lane, 64);
+    for (int kb = 0; kb < n_blocks; ++kb) {
+      while (__builtin_amdgcn_readfirstlane(flags[0]) < kb + 1) __builtin_amdgcn_s_sleep(1);
+      while (__builtin_amdgcn_readfirstlane(flags[3]) < kb - 1) __builtin_amdgcn_s_sleep(1);
+      ev2_lds_acquire();
+      const double *yin = yblk[kb & 1] + lane;
+      const int j = 38 * kb;
+      bl_tail_fifo f;
+      f.base = oblk[kb & 1] + lane;
+      f.stride = 64;
+      f.count = 0;
+      /* A song in its steady state for the whole block takes the straight-line path; the others —
+       * the first 40 steps (the same blocks for every song) and each song's own last dozen — take
+       * the step-by-step one.  With equal lengths the branch is wave-uniform; with mixed lengths
+       * both sides run (exec-masked) only for the block or two in which a song of the wave ends. */
+      if (bl_tail_ab::chunk_ok(j, N)) {
+        t.fast_chunk38(yin, 64, f.base, 64);
+        f.count = 38;
+      } else if (j < N) {
+        for (int q = 0; q < 38; ++q) {
+          const int jj = j + q;
+          if (jj < N) {
+            t.step(jj, yin[q * 64], f);
+            if (jj == N - 1) t.finish(f);
+          }
         }
       }
+      ocnt[kb & 1][lane] = f.count;
+      ev2_lds_release();
+      bl_wave_sync();
+      if (lane == 0) { flags[1] = kb + 1; flags[2] = kb + 1; }
     }
+    if (valid) {
+      bl_amd_song_result *r = res + sg.out_idx;
+      r->atk_sum = t.atk;
+      r->v.attack = bl_tail_attack(t.atk, sg.n);
+    }
+    return;
+  }
+
+  /* ---- o1 -> box 2 -> peaks ---- */
+  bl_tail_c c;
+  c.init(sg.nb_frames, rings_c + lane, 64);
+  for (int kb = 0; kb < n_blocks; ++kb) {
+    while (__builtin_amdgcn_readfirstlane(flags[2]) < kb + 1) __builtin_amdgcn_s_sleep(1);
+    ev2_lds_acquire();
+    const double *oin = oblk[kb & 1] + lane;
+    const int cnt = ocnt[kb & 1][lane];
+    if (cnt == 38 && c.chunk_ok()) {
+      c.fast_chunk38(oin, 64);
+    } else {
+      for (int q = 0; q < BL_TAIL_OMAX; ++q)
+        if (q < cnt) c.push(oin[q * 64]);
+    }
+    if (valid && c.taken == N && cnt > 0) c.finish(); /* the block that delivered the song's last output */
     ev2_lds_release();
     bl_wave_sync();
-    if (lane == 0) flags[1] = kb + 1;
+    if (lane == 0) flags[3] = kb + 1;
   }
   if (!valid) return;
   bl_amd_song_result *r = res + sg.out_idx;
-  r->beat = t.beat();
-  r->atk_sum = t.atk;
-  r->v.tempo = bl_tail_tempo(t.beat(), sg.duration);
-  r->v.attack = bl_tail_attack(t.atk, sg.n);
+  r->beat = c.beat();
+  r->v.tempo = bl_tail_tempo(c.beat(), sg.duration);
   (void)what;
 }
 
@@ -1346,7 +1381,7 @@ int blk_analyze(const blk_analyze_args &a) {
     }
     {
       Mark m(a.mark, a.mark_user, PK_TAIL, ts);
-      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(128), 0, ts, a.songs, a.lc, n_songs, a.results,
+      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(192), 0, ts, a.songs, a.lc, n_songs, a.results,
                          what);
     }
     if (tail_async) BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));

@@ -204,11 +204,13 @@ struct bl_tail {
 };
 
 /*
- * The same stream cut in two at y_j, for two cooperating waves (k_env_tail): the recurrence
- * is a chain of 8 dependent operations per step, everything downstream of y_j is ~30 more;
- * one wave per 64 songs issues both in order (~340 cycles per step), two waves overlap
- * them.  bl_tail above is the plain one-step-at-a-time form; bl_tail_iir + bl_tail_post
- * produce bit for bit the same (tests/host/test_tail_host.cpp runs both against the oracle).
+ * The same stream cut in three for three cooperating waves (k_env_tail): the recurrence
+ * (bl_tail_iir: a chain of 8 dependent operations per step), the onset weighting and first box
+ * filter (bl_tail_ab) and the second box filter with the peak test (bl_tail_c).  One wave per 64
+ * songs issuing everything in order needed ~340 cycles per step, two waves (recurrence |
+ * the rest) ~170; with three the recurrence's own chain (~90 cycles) is what is left.  bl_tail above
+ * is the plain one-step-at-a-time form; the three stages produce bit for bit the same
+ * (tests/host/test_tail_host.cpp runs both against the oracle).
  */
 struct bl_tail_iir {
   double x2, x4, x6;             /* even inputs x[j-2], x[j-4], x[j-6]; odd ones are stuffed zeros */
@@ -244,15 +246,31 @@ struct bl_tail_iir {
   }
 };
 
-struct bl_tail_post {
+/* A stream of doubles in LDS, written by one wave and read by the next: slot q of a lane is
+ * base[q * stride] */
+struct bl_tail_fifo {
+  double *base;
+  int stride, count;
+  BL_THD void push(double v) {
+    base[count * stride] = v;
+    ++count;
+  }
+};
+
+/*
+ * Stage "AB": y_j -> onset difference, weighting, atk, first box filter -> the stream o1 of box-1
+ * outputs (ref :221-263, :267-268).  Its outputs go to a sink (a bl_tail_fifo in the kernel, the
+ * next stage directly in the host test): one per step in the steady state, several at the edges
+ * (see bl_box19).
+ */
+struct bl_tail_ab {
   double yp; /* y[j-1] */
   double atk;
   bl_box19<true> box1;
-  bl_tail_stage2 st2;
   double *ring1, *olds1;
   int stride, N;
 
-  /* scratch: 19 + 10 + 19 doubles per song, element e at scratch[e * stride] */
+  /* scratch: 19 + 10 doubles per song, element e at scratch[e * stride] */
   BL_THD void init(int nb_frames, double *scratch, int stride_) {
     yp = 0;
     atk = 0;
@@ -260,17 +278,13 @@ struct bl_tail_post {
     stride = stride_;
     ring1 = scratch;
     olds1 = scratch + 19 * stride_;
-    st2.ring = scratch + 29 * stride_;
-    st2.stride = stride_;
     box1.init(N);
-    st2.box.init(N);
-    st2.peaks.init();
   }
 
-  /* Steady state: for 40 <= j <= N - 12 every conditional of step() is decided (both box
-   * filters and the peak detector emit exactly one value per step; box 2 lags box 1 by 9
-   * inputs and the peak detector by 18).  A block of 38 = 2 * 19 steps is two full turns of
-   * both rings, so they can live in registers and come back to the slots they left. */
+  /* Steady state: for 40 <= j and j + 1 <= N - 12 every conditional of step() is decided and box 1
+   * emits exactly one value per step.  A block of 38 = 2 * 19 steps is two full turns of the ring,
+   * so it can live in registers and come back to the slots it left; at least 11 generic steps
+   * follow any such block, which refill the 10 `old` cells that the block does not maintain. */
   BL_THD static bool steady(int j, int n) { return (j & 1) == 0 && j >= 40 && j + 1 <= n - 12; }
   BL_THD static bool chunk_ok(int j, int n) { return steady(j, n) && steady(j + 36, n); }
 
@@ -280,7 +294,7 @@ struct bl_tail_post {
   }
 
   /* one step j = 0..N-1 from y_j (ref :221-263) */
-  BL_THD void step(int j, double y) {
+  template <typename SINK> BL_THD void step(int j, double y, SINK &sink) {
     double dj;
     if (j == 0) dj = y;
     else { dj = y - yp; dj = dj > 0 ? dj : 0; }
@@ -288,19 +302,15 @@ struct bl_tail_post {
     yp = y;
     double ss = 0;
     if (j <= N - 2) { atk += wa; ss = wa; }
-    box1.push(ss, wa, ring1, olds1, stride, st2);
+    box1.push(ss, wa, ring1, olds1, stride, sink);
   }
+  template <typename SINK> BL_THD void finish(SINK &sink) { box1.finish(ring1, olds1, stride, sink); }
 
-  /* One steady step with the two box-filter rings held in registers (ra / rb are the 19 most
-   * recent inputs of box 1 / box 2 in ring order, P the static ring slot), cut into three stages
-   * with no arithmetic in common:
-   *   A  y_s -> wa_s (onset difference, weighting), atk        carries yp, atk
-   *   B  wa_s -> o1_s (box 1)                                  carries box1.run, ra
-   *   C  o1_s -> o2_s (box 2) -> peak test                     carries box 2's run, rb, p1, p2
-   * A GPU wave issues in order, and written step after step the ~20 operations of a step form one
-   * dependent chain (227 cycles per step measured against ~100 of issue).  reg_pipe() runs stage
-   * A of step s + 2, B of step s + 1 and C of step s side by side: three independent chains in
-   * flight, the same operations on the same operands in every one of them. */
+  /* One steady step with the ring in registers (ra: the 19 most recent inputs of box 1 in ring
+   * order, P the static slot), as two stages with no arithmetic in common — A: y_s -> wa_s, atk;
+   * B: wa_s -> o1_s.  A GPU wave issues in order and is alone on its SIMD here: written step after
+   * step the operations of a step form one dependent chain.  reg_pipe() runs A of step s + 1
+   * beside B of step s: the same operations on the same operands, two chains in flight. */
   template <int P> BL_THD double stage_a(double y) {
     double dj = y - yp;
     dj = dj > 0 ? dj : 0;
@@ -315,67 +325,115 @@ struct bl_tail_post {
     ra[P] = wa;
     return BL_DIV19(box1.run);
   }
-  template <int P> BL_THD void stage_c(double o1, double (&rb)[BL_BOX]) {
-    st2.box.run -= rb[P];
-    st2.box.run += o1;
-    rb[P] = o1;
-    const double o2 = BL_DIV19(st2.box.run);
-    const float epsilon = 0.000001f;
-    const double dl = st2.peaks.p1 - st2.peaks.p2, dr = st2.peaks.p1 - o2;
-    st2.peaks.beat += (dl > epsilon && dr > epsilon) ? 1 : 0;
-    st2.peaks.p2 = st2.peaks.p1;
-    st2.peaks.p1 = o2;
-  }
-  /* pipeline slot T: stage A of step T, stage B of step T - 1, stage C of step T - 2 */
-  template <int T> BL_THD void reg_pipe(const double *yin, int ystride, double (&ra)[BL_BOX],
-                                        double (&rb)[BL_BOX], double (&wa)[3], double (&o1)[3]) {
-    if constexpr (T < 2 * BL_BOX + 2) {
-      if constexpr (T >= 2) stage_c<(T - 2) % BL_BOX>(o1[(T - 2) % 3], rb);
-      if constexpr (T >= 1 && T - 1 < 2 * BL_BOX) o1[(T - 1) % 3] = stage_b<(T - 1) % BL_BOX>(wa[(T - 1) % 3], ra);
-      if constexpr (T < 2 * BL_BOX) wa[T % 3] = stage_a<T % BL_BOX>(yin[T * ystride]);
-      reg_pipe<T + 1>(yin, ystride, ra, rb, wa, o1);
+  template <int T>
+  BL_THD void reg_pipe(const double *yin, int ystride, double *o1out, int ostride, double (&ra)[BL_BOX],
+                       double (&wa)[2]) {
+    if constexpr (T < 2 * BL_BOX + 1) {
+      if constexpr (T >= 1) o1out[(T - 1) * ostride] = stage_b<(T - 1) % BL_BOX>(wa[(T - 1) % 2], ra);
+      if constexpr (T < 2 * BL_BOX) wa[T % 2] = stage_a<T % BL_BOX>(yin[T * ystride]);
+      reg_pipe<T + 1>(yin, ystride, o1out, ostride, ra, wa);
     }
   }
 
-  /* 38 steady steps y_j .. y_(j+37) at yin[s * ystride]; requires chunk_ok(j, N) */
-  BL_THD void fast_chunk38(const double *yin, int ystride) {
-    double ra[BL_BOX], rb[BL_BOX];
+  /* 38 steady steps y_j .. y_(j+37) at yin[s * ystride] -> 38 box-1 outputs at o1out[s * ostride];
+   * requires chunk_ok(j, N) */
+  BL_THD void fast_chunk38(const double *yin, int ystride, double *o1out, int ostride) {
+    double ra[BL_BOX];
     {
-      int sa = box1.s19, sb = st2.box.s19;
+      int sa = box1.s19;
 #pragma unroll
       for (int k = 0; k < BL_BOX; ++k) {
         ra[k] = ring1[sa * stride];
-        rb[k] = st2.ring[sb * stride];
         sa = sa == BL_BOX - 1 ? 0 : sa + 1;
-        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
       }
     }
-    double wa[3], o1[3];
-    reg_pipe<0>(yin, ystride, ra, rb, wa, o1);
+    double wa[2];
+    reg_pipe<0>(yin, ystride, o1out, ostride, ra, wa);
     {
-      int sa = box1.s19, sb = st2.box.s19;
+      int sa = box1.s19;
 #pragma unroll
       for (int k = 0; k < BL_BOX; ++k) {
         ring1[sa * stride] = ra[k];
-        st2.ring[sb * stride] = rb[k];
         sa = sa == BL_BOX - 1 ? 0 : sa + 1;
-        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
       }
     }
     box1.t += 38;
-    st2.box.t += 38;
-    st2.peaks.i += 38;
-    /* the skipped olds1 stores are all overwritten before finish() reads them: at least
-     * 11 generic steps follow any chunk (steady), olds1 holds 10 */
     box1.s10 = (box1.s10 + 8) % 10;
-    st2.box.s10 = (st2.box.s10 + 8) % 10;
   }
+};
 
-  BL_THD void finish() {
-    box1.finish(ring1, olds1, stride, st2);
-    st2.box.finish(st2.ring, (const double *)0, stride, st2.peaks);
+/*
+ * Stage "C": the stream o1 -> second box filter -> peak test (ref :269-280).  push() takes the
+ * box-1 outputs in index order; after the N-th one finish() flushes the filter's tail.
+ */
+struct bl_tail_c {
+  bl_box19<false> box;
+  bl_peaks peaks;
+  double *ring;
+  int stride, N, taken; /* taken: box-1 outputs consumed so far */
+
+  /* scratch: 19 doubles per song */
+  BL_THD void init(int nb_frames, double *scratch, int stride_) {
+    N = 2 * nb_frames;
+    stride = stride_;
+    ring = scratch;
+    taken = 0;
+    box.init(N);
+    peaks.init();
   }
-  BL_THD int beat() const { return st2.peaks.beat; }
+  BL_THD void push(double v) {
+    box.push(v, 0.0, ring, (double *)0, stride, peaks);
+    ++taken;
+  }
+  BL_THD void finish() { box.finish(ring, (const double *)0, stride, peaks); }
+  BL_THD int beat() const { return peaks.beat; }
+
+  /* 38 more inputs keep box 2 in its steady state (ring full, one output per input, ref :28-32) and
+   * the peak detector past its first two values */
+  BL_THD bool chunk_ok() const { return taken >= BL_BOX && taken + 37 <= N - 2; }
+
+  template <int P> BL_THD void stage_c(double o1, double (&rb)[BL_BOX]) {
+    box.run -= rb[P];
+    box.run += o1;
+    rb[P] = o1;
+    const double o2 = BL_DIV19(box.run);
+    const float epsilon = 0.000001f;
+    const double dl = peaks.p1 - peaks.p2, dr = peaks.p1 - o2;
+    peaks.beat += (dl > epsilon && dr > epsilon) ? 1 : 0;
+    peaks.p2 = peaks.p1;
+    peaks.p1 = o2;
+  }
+  template <int T> BL_THD void reg_steps(const double *o1in, int istride, double (&rb)[BL_BOX]) {
+    if constexpr (T < 2 * BL_BOX) {
+      stage_c<T % BL_BOX>(o1in[T * istride], rb);
+      reg_steps<T + 1>(o1in, istride, rb);
+    }
+  }
+  /* 38 steady inputs at o1in[s * istride]; requires chunk_ok() */
+  BL_THD void fast_chunk38(const double *o1in, int istride) {
+    double rb[BL_BOX];
+    {
+      int sb = box.s19;
+#pragma unroll
+      for (int k = 0; k < BL_BOX; ++k) {
+        rb[k] = ring[sb * stride];
+        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
+      }
+    }
+    reg_steps<0>(o1in, istride, rb);
+    {
+      int sb = box.s19;
+#pragma unroll
+      for (int k = 0; k < BL_BOX; ++k) {
+        ring[sb * stride] = rb[k];
+        sb = sb == BL_BOX - 1 ? 0 : sb + 1;
+      }
+    }
+    box.t += 38;
+    box.s10 = (box.s10 + 8) % 10;
+    peaks.i += 38;
+    taken += 38;
+  }
 };
 
 /* ref src/tempo_atk_sort.c:186-188 with mu = 100.0f; log101 = log(1 + mu) */

@@ -27,23 +27,38 @@ static int check(unsigned seed, unsigned rate, unsigned ch, unsigned secs, unsig
   t.finish();
   float tempo = bl_tail_tempo(t.beat(), secs), attack = bl_tail_attack(t.atk, (int)n);
   int ok = t.beat() == r.beat && t.atk == r.atk_sum && tempo == r.tempo && attack == r.attack;
-  // the two-stage form (recurrence | everything after y_j) used by k_env_tail: 38-step blocks
-  // from j = 0, register-ring chunks where the whole block is in the steady state
+  // the three-stage form used by k_env_tail (recurrence | weighting + box 1 | box 2 + peaks):
+  // 38-step blocks from j = 0 with a FIFO of up to 48 box-1 outputs per block between the last
+  // two, register-ring chunks wherever a stage is in its steady state for the whole block
   {
-    std::vector<double> scratch2(48), yv(N + 38, 0.0);
+    std::vector<double> s_ab(29), s_c(19), yv(N + 38, 0.0), fifo(48);
     bl_tail_iir a;
-    bl_tail_post b;
+    bl_tail_ab ab;
+    bl_tail_c c;
     a.init();
-    b.init(r.nb_frames, scratch2.data(), 1);
+    ab.init(r.nb_frames, s_ab.data(), 1);
+    c.init(r.nb_frames, s_c.data(), 1);
     for (int j = 0; j < N; j += 2) a.pair(bl_tail_compress((double)en[j / 2], log101), yv[j], yv[j + 1]);
     for (int j = 0; j < N; j += 38) {
-      if (use_fast && bl_tail_post::chunk_ok(j, N)) b.fast_chunk38(&yv[j], 1);
+      bl_tail_fifo f;
+      f.base = fifo.data(); f.stride = 1; f.count = 0;
+      if (use_fast && bl_tail_ab::chunk_ok(j, N)) {
+        ab.fast_chunk38(&yv[j], 1, fifo.data(), 1);
+        f.count = 38;
+      } else {
+        for (int q = j; q < j + 38 && q < N; ++q) {
+          ab.step(q, yv[q], f);
+          if (q == N - 1) ab.finish(f);
+        }
+      }
+      if (f.count > 48) { printf("  fifo overflow %d\n", f.count); ok = 0; }
+      if (use_fast && f.count == 38 && c.chunk_ok()) c.fast_chunk38(fifo.data(), 1);
       else
-        for (int q = j; q < j + 38 && q < N; ++q) b.step(q, yv[q]);
+        for (int q = 0; q < f.count; ++q) c.push(fifo[q]);
+      if (c.taken == N) c.finish();
     }
-    b.finish();
-    const int ok2 = b.beat() == r.beat && b.atk == r.atk_sum;
-    if (!ok2) printf("  two-stage: beat %d atk %.17g MISMATCH\n", b.beat(), b.atk);
+    const int ok2 = c.beat() == r.beat && ab.atk == r.atk_sum && c.taken == N;
+    if (!ok2) printf("  three-stage: beat %d atk %.17g taken %d MISMATCH\n", c.beat(), ab.atk, c.taken);
     ok &= ok2;
   }
   printf("seed %u n %u: beat %d/%d atk %.17g/%.17g tempo %g attack %g %s\n", seed, n, t.beat(),
