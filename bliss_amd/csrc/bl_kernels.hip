@@ -782,6 +782,15 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
    * the one sample that starts its own zero-state output (lane (g, l): sample l of window
    * g); both are fetched one round ahead so that the HBM latency hides behind the
    * arithmetic of the current round */
+  /* this lane's 15 pass-1 twiddles W256^(l k1) live in registers (60 of the 40 + 20 the kernel
+   * had to spare below 256): read from LDS inside the round, each one put its latency in front
+   * of four dependent operations.  Pinned, because hipcc would otherwise re-read LDS in the loop. */
+  c2d w1r[16];
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) {
+    w1r[k1] = tw256[k1 * 16 + l];
+    asm volatile("" : "+v"(w1r[k1].re), "+v"(w1r[k1].im));
+  }
   uint2 pre[5];
   short preh;
   /* The loads are unconditional (addresses clamped into the song, values zeroed by a
@@ -869,7 +878,14 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
       im[m1] = buf[s + 1];
     }
     ev2_wave_sync(); /* window data is in registers; the slice becomes exchange space */
-    bl_fft512_pass1<double>(l, re, im, tw256);
+    bl_fft16(re, im);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) { /* twiddles of pass 1 (bl_fft512_pass1, from registers) */
+      const int p_ = bl_pos16(k1);
+      double r_ = re[p_], i_ = im[p_];
+      bl_cmul(r_, i_, w1r[k1].re, w1r[k1].im);
+      if (l != 0) { re[p_] = r_; im[p_] = i_; }
+    }
     /* transposes: rows of 18 doubles so that a lane reads its row as 8 aligned 16-byte
      * loads (ds_read_b128: 4 LDS cycles; the ds_read2_b64 hipcc picks for unaligned pairs
      * costs 16).  Layouts checked with tools/lds_model.py: conflict-free. */
@@ -1386,7 +1402,7 @@ int blk_analyze(const blk_analyze_args &a) {
     }
     if (tail_async) BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
   }
-  /* The short amplitude kernel goes before the wide frequency pass: the tail's 54 KB
+  /* The short amplitude kernel goes before the wide frequency pass: the tail's 143 KB
    * workgroups only reach a CU when the dispatcher has no pending frequency workgroup to put
    * there, so they have to be resident before that pass begins (launched after it, the tail
    * started ~60 ms late and ~10 ms of it were exposed per 8 192 songs). */
