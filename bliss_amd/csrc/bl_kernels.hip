@@ -308,7 +308,11 @@ __global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__
   for (int g = 0; g < BL_AMP_PASSES; ++g) {
     const float *h = buf[cur] + 3;
     float *s = buf[cur ^ 1] + 3;
-    for (int i = tid; i < BL_HIST_BINS; i += 256) {
+    /* only bins that can still reach the integral window [BL_INT_LO, BL_INT_HI] through the passes
+     * that remain (3 bins per pass) are updated: from 3 807 of them in the first pass down to 2 001 */
+    const int reach = 3 * (BL_AMP_PASSES - 1 - g);
+    const int lo = max(BL_INT_LO - reach, 0), hi = min(BL_INT_HI + reach, BL_HIST_BINS - 1);
+    for (int i = lo + tid; i <= hi; i += 256) {
       /* ref :49-55: f32 sum left to right, times (double)(1/27), stored as f32 */
       float acc = h[i - 3] + (3 * h[i - 2]);
       acc = acc + (6 * h[i - 1]);
