@@ -884,12 +884,11 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
     ev2_wave_sync(); /* window data is in registers; the slice becomes exchange space */
     bl_fft16(re, im);
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) { /* twiddles of pass 1 (bl_fft512_pass1, from registers) */
-      const int p_ = bl_pos16(k1);
-      double r_ = re[p_], i_ = im[p_];
-      bl_cmul(r_, i_, w1r[k1].re, w1r[k1].im);
-      if (l != 0) { re[p_] = r_; im[p_] = i_; }
-    }
+    for (int k1 = 1; k1 < 16; ++k1) /* twiddles of pass 1 (bl_fft512_pass1), from registers */
+      bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w1r[k1].re, w1r[k1].im);
+    /* lane 0's twiddles are (1, -0): r * 1 - i * (-0) and r * (-0) + i * 1 are r and i exactly
+     * (only the sign of a zero can differ, and everything downstream is squared), so no select
+     * keeps them out of the multiply: that select was 60 v_cndmask per round */
     /* transposes: rows of 18 doubles so that a lane reads its row as 8 aligned 16-byte
      * loads (ds_read_b128: 4 LDS cycles; the ds_read2_b64 hipcc picks for unaligned pairs
      * costs 16).  Layouts checked with tools/lds_model.py: conflict-free. */
