@@ -14,21 +14,17 @@
  * format conversion (ref src/decode.c:323-346,388-392: libswresample): the
  * sample left-justified in 32 bits, arithmetic >> 16 — for 24-bit audio the
  * top 16 bits.  The FLAC decoder itself is pinned for 24-bit input by the
- * STREAMINFO MD5 of the reference's audio/song_s32*.flac
- * (tests/test_host_codelets.py); the narrowing step is libswresample's and
- * stays parity-unpinned.
+ * STREAMINFO MD5 of the reference's audio/song_s32*.flac (tests/test_ingest.py);
+ * the same-rate narrowing step is libswresample's and stays parity-unpinned.
  *
  * Sample rate.  The reference always hands 22 050 Hz PCM to the analyzers
- * (ref src/decode.c:7-9,317-346), and every analyzer constant assumes it.  There
- * is no resampler here (libswresample's arithmetic cannot be reproduced), so a
- * file at any other rate FAILS (BL_UNEXPECTED, message on stderr) unless the
- * caller opted in with bl_amd_decode_allow_native_rate(1) /
- * BL_AMD_ALLOW_NATIVE_RATE=1; then it is analysed at its native rate with
- * resampled = 0, and its force vector is not comparable with the reference's.
- * Sources that are already 22 050 Hz s16 (the reference's own audio/song.flac)
- * decode to the byte-identical sample_array (MD5 pinned by ref
- * tests/test_decode.c:16-17).  Mono files stay mono (the reference up-mixes
- * through the resampler, ref src/decode.c:338).
+ * (ref src/decode.c:7-9,317-346), and every analyzer constant assumes it: a file at any other
+ * rate is converted (bl_resample.c, a restatement of libswresample's default resampler pinned
+ * by the digests of ref tests/test_decode.c:35-36,55-56) to 22 050 Hz stereo s16, resampled = 1.
+ * bl_amd_decode_allow_native_rate(1) / BL_AMD_ALLOW_NATIVE_RATE=1 switches the conversion off.
+ * Sources that are already 22 050 Hz s16 (the reference's own audio/song.flac) decode to the
+ * byte-identical sample_array (MD5 pinned by ref tests/test_decode.c:16-17); a 22 050 Hz mono
+ * file stays mono.
  */
 #include <ctype.h>
 #include <stdint.h>
@@ -38,6 +34,7 @@
 
 #include "bliss.h"
 #include "bliss_amd.h"
+#include "bl_resample.h"
 
 #define BL_DECODE_RATE 22050 /* ref src/decode.c:7 SAMPLE_RATE */
 
@@ -59,6 +56,47 @@ static inline int16_t narrow_sample(int32_t v, uint32_t bps) {
   if (bps > 16) return (int16_t)(v >> (bps - 16));
   return (int16_t)((uint32_t)v << (16 - bps));
 }
+
+/* Where the decoders put the interleaved samples: narrowed to s16 (the analyzers' format), or —
+ * for a source wider than 16 bits that still has to go through the rate converter —
+ * left-justified in 32 bits, which is what FFmpeg's decoders hand to libswresample. */
+typedef struct {
+  int16_t *p16;
+  int32_t *p32;
+  size_t n, cap;
+  int wide;
+  uint32_t bps; /* significant bits of the source */
+} pcm_sink;
+
+static int sink_reserve(pcm_sink *s, size_t more) {
+  if (s->n + more <= s->cap) return 0;
+  size_t cap = (s->cap + more) * 2;
+  if (s->wide) {
+    int32_t *np = (int32_t *)realloc(s->p32, cap * sizeof(int32_t) + 16);
+    if (!np) return -1;
+    s->p32 = np;
+  } else {
+    int16_t *np = (int16_t *)realloc(s->p16, cap * sizeof(int16_t) + 16);
+    if (!np) return -1;
+    s->p16 = np;
+  }
+  s->cap = cap;
+  return 0;
+}
+
+static inline void sink_put(pcm_sink *s, int32_t v) {
+  if (s->wide) s->p32[s->n++] = (int32_t)((uint32_t)v << (32 - s->bps));
+  else s->p16[s->n++] = narrow_sample(v, s->bps);
+}
+
+static void sink_free(pcm_sink *s) {
+  free(s->p16);
+  free(s->p32);
+  s->p16 = NULL;
+  s->p32 = NULL;
+}
+
+static int wants_rate_conversion(uint32_t rate);
 
 /* ----------------------------------------------------------------------- */
 typedef struct {
@@ -151,7 +189,7 @@ static uint32_t le32(const uint8_t *p) {
 static uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
 /* ------------------------------- WAV ----------------------------------- */
-static int decode_wav(const uint8_t *d, size_t len, struct bl_song *song) {
+static int decode_wav(const uint8_t *d, size_t len, struct bl_song *song, pcm_sink *sink) {
   if (len < 12 || memcmp(d, "RIFF", 4) || memcmp(d + 8, "WAVE", 4)) return BL_UNEXPECTED;
   size_t pos = 12;
   int have_fmt = 0;
@@ -173,15 +211,17 @@ static int decode_wav(const uint8_t *d, size_t len, struct bl_song *song) {
       uint32_t n = sz / bytes;
       n -= n % channels;
       if (n == 0) return BL_UNEXPECTED;
-      int16_t *pcm = (int16_t *)malloc((size_t)n * 2);
-      if (!pcm) return BL_UNEXPECTED;
+      sink->bps = bits;
+      sink->wide = bits > 16 && wants_rate_conversion(rate);
+      if (sink_reserve(sink, n)) return BL_UNEXPECTED;
       for (uint32_t i = 0; i < n; ++i) {
         const uint8_t *q = body + (size_t)bytes * i;
-        if (bits == 16) pcm[i] = (int16_t)le16(q);
-        else if (bits == 24) pcm[i] = (int16_t)(le16(q + 1));        /* top 16 of 24 */
-        else pcm[i] = (int16_t)(le16(q + 2));                         /* top 16 of 32 */
+        int32_t v;
+        if (bits == 16) v = (int16_t)le16(q);
+        else if (bits == 24) v = (int32_t)((le16(q + 1) << 8 | q[0]) << 8) >> 8;
+        else v = (int32_t)le32(q);
+        sink_put(sink, v);
       }
-      song->sample_array = (int8_t *)pcm;
       song->nSamples = (int)n;
       song->channels = (int)channels;
       song->sample_rate = (int)rate;
@@ -407,7 +447,8 @@ typedef struct {
   uint8_t stored[16];
 } flac_sig;
 
-static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, flac_sig *sig) {
+static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_sink *sink,
+                       flac_sig *sig) {
   if (len < 42 || memcmp(d, "fLaC", 4)) return BL_UNEXPECTED;
   size_t pos = 4;
   flac_info fi;
@@ -437,14 +478,14 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, flac_
     return BL_UNEXPECTED;
   size_t audio_start = pos;
 
-  size_t cap = fi.total ? (size_t)fi.total * fi.channels : (size_t)1 << 20;
-  int16_t *pcm = (int16_t *)malloc(cap * 2 + 16);
-  if (!pcm) return BL_UNEXPECTED;
-  size_t n = 0;
+  sink->bps = fi.bps;
+  sink->wide = fi.bps > 16 && wants_rate_conversion(fi.rate);
+  if (sink_reserve(sink, fi.total ? (size_t)fi.total * fi.channels / 2 + 8 : (size_t)1 << 19))
+    return BL_UNEXPECTED;
   uint32_t maxb = fi.max_block ? fi.max_block : 65535;
   int32_t *ch[2];
   ch[0] = (int32_t *)malloc(sizeof(int32_t) * (size_t)(maxb + 16) * 2);
-  if (!ch[0]) { free(pcm); return BL_UNEXPECTED; }
+  if (!ch[0]) return BL_UNEXPECTED;
   ch[1] = ch[0] + maxb + 16;
 
   static const uint32_t bs_tab[16] = {0,    192,  576,  1152, 2304, 4608, 0,     0,
@@ -486,12 +527,7 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, flac_
     br_align(&b);
     br_bits(&b, 16); /* CRC-16 (not verified) */
     pos = br_bytepos(&b);
-    if (n + (size_t)blocksize * nch > cap) {
-      cap = (cap + (size_t)blocksize * nch) * 2;
-      int16_t *np = (int16_t *)realloc(pcm, cap * 2 + 16);
-      if (!np) { rc = BL_UNEXPECTED; break; }
-      pcm = np;
-    }
+    if (sink_reserve(sink, (size_t)blocksize * nch)) { rc = BL_UNEXPECTED; break; }
     for (uint32_t i = 0; i < blocksize; ++i) {
       int32_t l = ch[0][i], r = nch == 2 ? ch[1][i] : 0;
       if (chan == 8) r = l - r;                 /* left/side  */
@@ -501,8 +537,8 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, flac_
         l = (mid + side) >> 1;
         r = (mid - side) >> 1;
       }
-      pcm[n++] = narrow_sample(l, bps);
-      if (nch == 2) pcm[n++] = narrow_sample(r, bps);
+      sink_put(sink, l);
+      if (nch == 2) sink_put(sink, r);
       if (sig) { /* little-endian, (bps + 7) / 8 bytes per sample, interleaved */
         uint8_t raw[8];
         const uint32_t nb = (bps + 7) / 8;
@@ -515,8 +551,8 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, flac_
     }
   }
   free(ch[0]);
-  if (rc != BL_OK || n == 0) { free(pcm); return BL_UNEXPECTED; }
-  song->sample_array = (int8_t *)pcm;
+  const size_t n = sink->n;
+  if (rc != BL_OK || n == 0) return BL_UNEXPECTED;
   song->nSamples = (int)n;
   song->channels = (int)fi.channels;
   song->sample_rate = (int)fi.rate;
@@ -530,6 +566,10 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, flac_
     song->bitrate = secs > 0 ? (int)((double)len * 8.0 / secs) : 0;
   }
   return BL_OK;
+}
+
+static int wants_rate_conversion(uint32_t rate) {
+  return rate != BL_DECODE_RATE && !native_rate_allowed();
 }
 
 /* ref include/bliss.h:234-235 / src/decode.c:27-213 */
@@ -550,19 +590,41 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
     return BL_UNEXPECTED;
   }
   int rc = BL_UNEXPECTED;
-  if (len >= 4 && !memcmp(data, "fLaC", 4)) rc = decode_flac(data, len, song, NULL);
-  else if (len >= 12 && !memcmp(data, "RIFF", 4)) rc = decode_wav(data, len, song);
+  pcm_sink sink;
+  memset(&sink, 0, sizeof sink);
+  if (len >= 4 && !memcmp(data, "fLaC", 4)) rc = decode_flac(data, len, song, &sink, NULL);
+  else if (len >= 12 && !memcmp(data, "RIFF", 4)) rc = decode_wav(data, len, song, &sink);
   else fprintf(stderr, "Unsupported container (WAV integer PCM / FLAC only): %s\n", filename);
   free(data);
-  if (rc == BL_OK && song->sample_rate != BL_DECODE_RATE && !native_rate_allowed()) {
-    fprintf(stderr,
-            "bliss_amd: %s is %d Hz; the analyzers expect %d Hz PCM and this library has no resampler "
-            "(bl_amd_decode_allow_native_rate(1) analyses it at its native rate)\n",
-            filename, song->sample_rate, BL_DECODE_RATE);
-    free(song->sample_array);
-    song->sample_array = NULL;
-    rc = BL_UNEXPECTED;
+  if (rc == BL_OK && wants_rate_conversion((uint32_t)song->sample_rate)) {
+    /* ref src/decode.c:317-346: anything that is not 22 050 Hz s16 goes through the rate
+     * converter and comes out as 22 050 Hz stereo s16 */
+    int16_t *out = NULL;
+    size_t out_frames = 0;
+    const size_t frames = sink.n / (size_t)song->channels;
+    rc = bl_resample_to_stereo_s16(sink.wide ? (const void *)sink.p32 : (const void *)sink.p16,
+                                   sink.wide, frames, song->channels, song->sample_rate,
+                                   BL_DECODE_RATE, &out, &out_frames);
+    if (rc == BL_OK && (out_frames == 0 || out_frames * 2 > (size_t)INT32_MAX)) {
+      free(out);
+      rc = BL_UNEXPECTED;
+    }
+    if (rc != BL_OK) {
+      fprintf(stderr, "bliss_amd: could not convert %s from %d Hz to %d Hz\n", filename,
+              song->sample_rate, BL_DECODE_RATE);
+    } else {
+      sink_free(&sink);
+      song->sample_array = (int8_t *)out;
+      song->nSamples = (int)(out_frames * 2);
+      song->channels = 2;
+      song->sample_rate = BL_DECODE_RATE;
+      song->resampled = 1;
+    }
+  } else if (rc == BL_OK) {
+    song->sample_array = (int8_t *)sink.p16;
+    sink.p16 = NULL;
   }
+  sink_free(&sink);
   if (rc != BL_OK) {
     free(song->artist); free(song->title); free(song->album);
     free(song->tracknumber); free(song->genre);
@@ -593,9 +655,11 @@ int bl_amd_flac_verify(const char *filename, uint8_t computed[16], uint8_t store
   flac_sig sig;
   md5_init(&sig.md);
   memset(sig.stored, 0, sizeof sig.stored);
-  const int rc = decode_flac(data, len, &song, &sig);
+  pcm_sink sink;
+  memset(&sink, 0, sizeof sink);
+  const int rc = decode_flac(data, len, &song, &sink, &sig);
   free(data);
-  free(song.sample_array);
+  sink_free(&sink);
   free(song.artist); free(song.title); free(song.album); free(song.tracknumber); free(song.genre);
   if (rc != BL_OK) return BL_UNEXPECTED;
   uint8_t got[16];

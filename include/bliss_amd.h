@@ -131,11 +131,11 @@ int bl_amd_analyze_corpus_multi(const int16_t *const *h_pcm, const int32_t *n_sa
                                 bl_amd_song_result *h_results, float *h_matrix);
 
 /* bl_audio_decode() follows the reference in always presenting 22 050 Hz PCM to the
- * analyzers (ref src/decode.c:7-9,317-346), but it has no resampler (libswresample's
- * arithmetic cannot be reproduced here): a file at another rate fails with BL_UNEXPECTED
- * unless the caller opts in to analysing it at its native rate (allow != 0; also
- * BL_AMD_ALLOW_NATIVE_RATE=1).  Force vectors of such files are not comparable with the
- * reference's. */
+ * analyzers (ref src/decode.c:7-9,317-346): a file at another rate, or wider than 16 bits at
+ * another rate, goes through a restatement of libswresample's default converter and comes out
+ * as 22 050 Hz stereo s16 (resampled = 1).  allow != 0 (also BL_AMD_ALLOW_NATIVE_RATE=1)
+ * switches that off: the file is handed over at its own rate, narrowed to s16 only, and its
+ * force vector is not comparable with the reference's. */
 void bl_amd_decode_allow_native_rate(int allow);
 /* Integrity check of the FLAC decoder behind bl_audio_decode: decodes `filename` and compares
  * the MD5 of the decoded samples at their native width (before the narrowing to s16) with the

@@ -118,6 +118,26 @@ def test_reference_golden_through_bl_analyze(gpu_lib):
     gpu_lib.bl_free_song(C.byref(song))
 
 
+def test_reference_golden_s32_through_bl_analyze(gpu_lib):
+    """ref tests/test_analyze.c:59-89 (test_analyze_s32): the 48 kHz / 24-bit fixture goes through
+    the rate converter (digest of ref tests/test_decode.c:35-36) and the GPU analyzers."""
+    song = _lib.BlSong()
+    rc = gpu_lib.bl_analyze(os.path.join(HERE, "golden", "song_s32.flac").encode(), C.byref(song))
+    assert rc == _lib.BL_CALM
+    gold = dict(force=-20.821571, tempo=-8.218182, amplitude=-10.641695, frequency=-10.179875,
+                attack=-15.561186)
+    assert abs(song.force - gold["force"]) <= 1e-5
+    for k in ("tempo", "amplitude", "frequency", "attack"):
+        assert abs(getattr(song.force_vector, k) - gold[k]) <= 1e-5, k
+    assert (song.channels, song.nSamples, song.sample_rate, song.nb_bytes_per_sample,
+            song.duration, song.resampled) == (2, 488140, 22050, 2, 11, 1)
+    assert (song.artist, song.title, song.album, song.tracknumber, song.genre) == \
+        (b"David TMX", b"Renaissance", b"Renaissance", b"02", b"Pop")
+    pcm = np.ctypeslib.as_array(C.cast(song.sample_array, C.POINTER(C.c_int16)), shape=(song.nSamples,))
+    assert hashlib.md5(pcm.tobytes()).hexdigest() == "eb9f31a7b9ed022d66ff82b76e7c3c18"
+    gpu_lib.bl_free_song(C.byref(song))
+
+
 def test_distance_file_and_errors(gpu_lib, tmp_path):
     f = os.path.join(HERE, "golden", "song.flac").encode()
     s1, s2 = _lib.BlSong(), _lib.BlSong()

@@ -1,6 +1,7 @@
 """Host ingest (bl_audio_decode) beyond the 16-bit fixture: 24-bit FLAC pinned by the STREAMINFO
-signature of the reference's own audio/song_s32*.flac, the S32 -> S16 narrowing, the sample-rate
-policy, WAV 24/32-bit, and malformed metadata.  No GPU involved."""
+signature of the reference's own audio/song_s32*.flac, the rate converter pinned by the digests the
+reference's tests hold for the same two files, the S32 -> S16 narrowing, WAV 24/32-bit, and
+malformed metadata.  No GPU involved."""
 import ctypes as C
 import hashlib
 import os
@@ -101,13 +102,42 @@ def test_flac_decoder_matches_streaminfo_signature(lib, name, stored):
         assert bytes(got).hex() == stored
 
 
-def test_sample_rate_policy(lib):
-    """48 kHz sources: the reference resamples to 22 050 Hz (ref src/decode.c:317-346); this
-    library cannot and must say so instead of analysing at the wrong rate."""
-    p = os.path.join(GOLD, "song_s32.flac")
+# ref tests/test_decode.c:35-36,55-56: MD5 of the 22 050 Hz stereo s16 audio the reference's decoder
+# (libswresample behind it) produces for its two 48 kHz / 24-bit fixtures
+RESAMPLED_MD5 = {"song_s32.flac": "eb9f31a7b9ed022d66ff82b76e7c3c18",
+                 "song_s32_mono.flac": "747dbfcd75bebc23ebe2024935aede36"}
+
+
+@pytest.mark.parametrize("name", sorted(RESAMPLED_MD5))
+def test_rate_conversion_reproduces_reference_digest(lib, name):
+    """48 kHz / 24 bit -> 22 050 Hz stereo s16 (ref src/decode.c:317-346, 379-401): byte-identical
+    to what the reference's tests pin, metadata as ref tests/test_analyze.c:69-88."""
     lib.bl_amd_decode_allow_native_rate(0)
-    rc, _, _ = _decode(lib, p)
-    assert rc == _lib.BL_UNEXPECTED
+    rc, pcm, meta = _decode(lib, os.path.join(GOLD, name))
+    assert rc == _lib.BL_OK
+    assert hashlib.md5(pcm.tobytes()).hexdigest() == RESAMPLED_MD5[name]
+    assert pcm.size == 488140 and meta["channels"] == 2 and meta["rate"] == 22050
+    assert meta["nb"] == 2 and meta["resampled"] == 1 and meta["duration"] == 11
+    assert meta["title"] == b"Renaissance"
+    if "mono" in name:
+        assert np.array_equal(pcm[0::2], pcm[1::2])
+
+
+def test_oracle_reproduces_reference_goldens_of_the_resampled_fixture(lib, oracle):
+    """ref tests/test_analyze.c:59-68 (EPSILON 1e-5): second pin of the oracle, on the output of the
+    rate converter."""
+    rc, pcm, meta = _decode(lib, os.path.join(GOLD, "song_s32.flac"))
+    assert rc == _lib.BL_OK
+    r = oracle.analyze(pcm, 2, meta["duration"])
+    gold = dict(force=-20.821571, tempo=-8.218182, amplitude=-10.641695, frequency=-10.179875,
+                attack=-15.561186)
+    for k, want in gold.items():
+        assert abs(r[k] - want) <= 1e-5, (k, r[k], want)
+
+
+def test_native_rate_opt_in(lib):
+    """With the opt-in the file is handed over at its own rate, narrowed, not converted."""
+    p = os.path.join(GOLD, "song_s32.flac")
     lib.bl_amd_decode_allow_native_rate(1)
     try:
         rc, pcm, meta = _decode(lib, p)
@@ -118,6 +148,83 @@ def test_sample_rate_policy(lib):
         assert rc == _lib.BL_OK and meta["channels"] == 1 and mono.size == 531307
     finally:
         lib.bl_amd_decode_allow_native_rate(0)
+
+
+def _write_wav16(path, pcm, channels, rate):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(np.asarray(pcm, dtype=np.int16).tobytes())
+
+
+def _kaiser_bank(in_rate, out_rate=22050):
+    """The converter's filter design restated in numpy (double), for the s16 checks below:
+    Kaiser(9)-windowed sinc, cutoff 0.97, ceil(32 / factor) taps made even, one row per phase of
+    out/in in lowest terms, normalised by the DC gain of phase 0."""
+    from math import gcd
+    factor = min(out_rate * 0.97 / in_rate, 1.0)
+    taps = int(np.ceil(32 / factor)); taps += taps & 1
+    phases = out_rate // gcd(out_rate, in_rate)
+    assert phases <= 1024
+    center = (taps - 1) // 2
+    i = np.arange(taps)[None, :]
+    ph = np.arange(phases)[:, None]
+    x = np.pi * ((i - center) - ph / phases) * factor
+    y = np.where(x == 0, 1.0, np.sin(x) / np.where(x == 0, 1.0, x))
+    w = 2.0 * x / (factor * taps * np.pi)
+    y = y * np.i0(9.0 * np.sqrt(np.maximum(1 - w * w, 0)))
+    return y / y[0].sum(), center, phases
+
+
+@pytest.mark.parametrize("in_rate", [44100, 48000, 32000, 96000])
+def test_s16_rate_conversion_against_numpy_restatement(lib, tmp_path, in_rate):
+    """16-bit sources take the integer path (Q15 coefficients, int32 accumulator, rounding
+    (v + 2^14) >> 15): compared sample for sample with a numpy restatement away from the edges."""
+    from math import gcd
+    rng = np.random.default_rng(in_rate)
+    frames = 3 * in_rate + 17
+    t = np.arange(frames)
+    sig = (9000 * np.sin(2 * np.pi * 440 * t / in_rate) + 3000 * np.sin(2 * np.pi * 5000 * t / in_rate)
+           + rng.integers(-500, 500, frames)).astype(np.int16)
+    stereo = np.stack([sig, (sig // 2 + 100).astype(np.int16)], axis=1)
+    p = tmp_path / "s.wav"
+    _write_wav16(p, stereo.reshape(-1), 2, in_rate)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["rate"] == 22050 and meta["resampled"] == 1 and meta["channels"] == 2
+    out = pcm.reshape(-1, 2)
+    assert abs(out.shape[0] - frames * 22050 / in_rate) <= 1.0
+    bank, center, phases = _kaiser_bank(in_rate)
+    q = np.clip(np.rint((bank * 32768).astype(np.float32)), -32768, 32767).astype(np.int64)
+    g = gcd(22050, in_rate)
+    step = in_rate // g                       # input advance per output, in units of 1/phases sample
+    taps = bank.shape[1]
+    for n in (40, 41, 1000, 12345, out.shape[0] - 60):
+        pos = n * step
+        s0, phs = pos // phases, pos % phases
+        for c in range(2):
+            win = stereo[s0 - center:s0 - center + taps, c].astype(np.int64)
+            want = int(np.clip(((win * q[phs]).sum() + (1 << 14)) >> 15, -32768, 32767))
+            assert out[n, c] == want, (in_rate, n, c)
+
+
+def test_rate_conversion_properties(lib, tmp_path):
+    """DC in -> the same DC out (coefficients sum to one), a mono source comes out as two equal
+    channels at gain 1/sqrt(2) (ref src/decode.c:338: out layout stereo), length follows the ratio."""
+    frames = 44100 * 2
+    p = tmp_path / "dc.wav"
+    _write_wav16(p, np.full(2 * frames, 12000, np.int16), 2, 44100)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and pcm.size == 2 * (frames // 2)
+    assert np.all(np.abs(pcm.astype(int) - 12000) <= 1)
+    _write_wav16(p, np.full(frames, 12000, np.int16), 1, 44100)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["channels"] == 2 and pcm.size == 2 * (frames // 2)
+    assert np.array_equal(pcm[0::2], pcm[1::2])
+    assert np.all(np.abs(pcm.astype(int) - round(12000 / np.sqrt(2))) <= 1)
+    # too short to fill the filter once: fails, does not crash
+    _write_wav16(p, np.zeros(2 * 20, np.int16), 2, 44100)
+    rc, _, _ = _decode(lib, p)
+    assert rc == _lib.BL_UNEXPECTED
 
 
 def test_24bit_flac_is_narrowed_with_shift(lib, tmp_path):
