@@ -40,6 +40,11 @@ class SongDesc(C.Structure):  # include/bliss_amd.h bl_amd_song_desc
                 ("channels", C.c_int32), ("duration", C.c_uint64)]
 
 
+class ResampleDesc(C.Structure):  # include/bliss_amd.h bl_amd_resample_desc
+    _fields_ = [("in_offset", C.c_uint64), ("out_offset", C.c_uint64), ("frames", C.c_int32),
+                ("channels", C.c_int32)]
+
+
 class SongResult(C.Structure):  # include/bliss_amd.h bl_amd_song_result
     _fields_ = [("v", ForceVector), ("force", C.c_float), ("calm_or_loud", C.c_int32),
                 ("status", C.c_int32), ("start", C.c_int32), ("end", C.c_int32),
@@ -83,6 +88,13 @@ SYMBOLS = {
     "bl_amd_analyze_batch_host_s32": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
                                                 _P(C.c_uint64), C.c_int, _P(SongResult)]),
     "bl_amd_narrow_s32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bl_amd_resample_out_frames": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "bl_amd_resample_host": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                       _P(_P(C.c_int16)), _P(C.c_size_t)]),
+    "bl_amd_resample_batch_device": (C.c_int, [C.c_void_p, C.c_int, _P(ResampleDesc), C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
+    "bl_amd_ctx_resample_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _P(ResampleDesc), C.c_int,
+                                                   C.c_int, C.c_void_p, C.c_void_p]),
     "bl_amd_analyze_corpus_multi": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32), _P(C.c_uint64),
                                               C.c_int, _P(C.c_int), C.c_int, C.c_int, _P(SongResult),
                                               _P(C.c_float)]),

@@ -182,6 +182,56 @@ def analyze_corpus_multi(pcm_list, channels, durations, devices, gather="rccl", 
     return results_to_numpy(bytes(out)), mat
 
 
+def resample_host(pcm, channels, in_rate):
+    """Interleaved int16 / int32 (left-justified) numpy PCM at in_rate Hz -> interleaved stereo int16
+    at 22 050 Hz, the conversion bl_audio_decode applies (include/bliss_amd.h)."""
+    lib = _lib.load()
+    pcm = np.ascontiguousarray(pcm)
+    if pcm.dtype not in (np.int16, np.int32):
+        raise TypeError("int16 or int32 PCM expected")
+    out = C.POINTER(C.c_int16)()
+    n = C.c_size_t(0)
+    _check(lib.bl_amd_resample_host(pcm.ctypes.data, int(pcm.dtype == np.int32), pcm.size // channels,
+                                    channels, in_rate, C.byref(out), C.byref(n)), "bl_amd_resample_host")
+    try:
+        return np.ctypeslib.as_array(out, shape=(2 * n.value,)).copy()
+    finally:
+        _libc_free(out)
+
+
+def _libc_free(ptr):
+    C.CDLL(None).free(C.cast(ptr, C.c_void_p))
+
+
+def resample_batch_device(d_in, frames, channels, in_rate, stream=None):
+    """Songs resident in HBM at in_rate Hz (one torch int16 or int32 CUDA tensor, song i = the next
+    frames[i] * channels[i] elements, starts rounded up to 8 elements) -> (int16 CUDA arena at
+    22 050 Hz stereo, SongDesc-ready list of (pcm_offset, n_samples)).  Asynchronous on `stream`."""
+    import torch
+    lib = _lib.load()
+    n = len(frames)
+    channels = [channels] * n if np.isscalar(channels) else list(channels)
+    desc = (_lib.ResampleDesc * n)()
+    in_off = out_off = 0
+    placed = []
+    for i, (fr, ch) in enumerate(zip(frames, channels)):
+        of = lib.bl_amd_resample_out_frames(int(fr), in_rate)
+        desc[i].in_offset, desc[i].out_offset = in_off, out_off
+        desc[i].frames, desc[i].channels = int(fr), int(ch)
+        placed.append((out_off, 2 * of))
+        in_off += (int(fr) * int(ch) + 7) & ~7
+        out_off += (2 * of + 7) & ~7
+    out = torch.zeros(out_off + 64, dtype=torch.int16, device=d_in.device)
+    s = stream.cuda_stream if stream is not None else torch.cuda.current_stream(d_in.device).cuda_stream
+    idx = d_in.device.index or 0
+    with torch.cuda.device(idx):
+        _check(lib.bl_amd_init(idx), "bl_amd_init")
+        _check(lib.bl_amd_resample_batch_device(d_in.data_ptr(), int(d_in.dtype == torch.int32), desc, n,
+                                                in_rate, out.data_ptr(), C.c_void_p(s)),
+               "bl_amd_resample_batch_device")
+    return out, placed
+
+
 def _matrix(fn_name, vecs):
     lib = _lib.load()
     v = np.ascontiguousarray(vecs, dtype=np.float32).reshape(-1, 4)

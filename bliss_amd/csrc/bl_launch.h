@@ -106,4 +106,29 @@ int blk_scan_one(hipStream_t s, const int16_t *pcm, const bl_dsong *d_songs, bl_
 int blk_variance_wrap_one(hipStream_t s, const int16_t *pcm, const bl_dsong *d_songs,
                           bl_dstats *d_stats, int n, int n_cu);
 
+/* ---- device rate converter (bl_rs_kernels.hip) ------------------------------ */
+
+#define BL_RS_MAX_DEVICES 16
+
+struct bl_rs_dsong {
+  unsigned long long in_off;  /* elements (int16 or int32) from the input base */
+  unsigned long long out_off; /* int16 elements from the output base, even */
+  int frames, channels;       /* input frames, 1 | 2 */
+  int out_frames, refl;       /* bl_rs_out_frames() */
+};
+
+struct bl_rs_geom {
+  int phase_count, taps, taps8, alloc, w0, span;
+  unsigned long long src_incr, dst_incr;
+};
+
+/* geometry + LDS budget of a plan (bl_resample.h); BL_UNEXPECTED when a tile's input span
+ * does not fit the LDS (input rates far above 192 kHz) */
+int blk_resample_geom(int phase_count, int taps, int alloc, int src_incr, int dst_incr, bl_rs_geom *g,
+                      size_t *lds_bytes, int *bank_in_lds);
+/* d_bank: phase_count rows of `alloc` 32-bit elements (float, or the Q15 coefficients as int) */
+int blk_resample(hipStream_t s, const void *d_in, int in_is_s32, const bl_rs_dsong *d_songs, int n_songs,
+                 int max_out_frames, const void *d_bank, const bl_rs_geom &g, size_t lds_bytes,
+                 int bank_in_lds, int16_t *d_out);
+
 #endif /* BL_LAUNCH_H_ */

@@ -43,12 +43,6 @@
 #define RS_CUTOFF 0.97
 #define RS_KAISER_BETA 9.0
 
-typedef struct {
-  int phase_count, taps, alloc;
-  int src_incr, dst_incr_div, dst_incr_mod;
-  float *fbank;   /* (phase_count + 1) rows of `alloc` */
-  int16_t *ibank;
-} rs_filter;
 
 /* modified Bessel function of the first kind, order 0 (power series; the window only needs it
  * to double precision, the coefficients are rounded to float / Q15 afterwards) */
@@ -68,15 +62,16 @@ static int64_t gcd64(int64_t a, int64_t b) {
   return a;
 }
 
-static void rs_filter_free(rs_filter *f) {
+void bl_rs_plan_free(bl_rs_plan *f) {
   free(f->fbank);
   free(f->ibank);
   f->fbank = NULL;
   f->ibank = NULL;
 }
 
-static int rs_filter_build(rs_filter *f, int out_rate, int in_rate, int want_float) {
+int bl_rs_plan_geometry(bl_rs_plan *f, int out_rate, int in_rate) {
   memset(f, 0, sizeof *f);
+  if (out_rate <= 0 || in_rate <= 0) return -1;
   double factor = (double)out_rate * RS_CUTOFF / (double)in_rate;
   if (factor > 1.0) factor = 1.0;
   int phase_count = 1 << RS_PHASE_SHIFT;
@@ -102,14 +97,24 @@ static int rs_filter_build(rs_filter *f, int out_rate, int in_rate, int want_flo
   if (den > INT32_MAX / 2) return -1;
   while (den < (1 << 20) && num < (1 << 20)) { den *= 2; num *= 2; }
   f->src_incr = (int)num;
+  f->dst_incr = (int)den;
   f->dst_incr_div = (int)(den / num);
   f->dst_incr_mod = (int)(den % num);
+  return 0;
+}
+
+int bl_rs_plan_build(bl_rs_plan *f, int out_rate, int in_rate, int want_float) {
+  if (bl_rs_plan_geometry(f, out_rate, in_rate)) return -1;
+  f->is_float = want_float != 0;
+  const int phase_count = f->phase_count, taps = f->taps, alloc = f->alloc;
+  double factor = (double)out_rate * RS_CUTOFF / (double)in_rate;
+  if (factor > 1.0) factor = 1.0;
 
   const size_t rows = (size_t)phase_count + 1;
   if (want_float) f->fbank = (float *)calloc(rows * alloc + 16, sizeof(float));
   else f->ibank = (int16_t *)calloc(rows * alloc + 16, sizeof(int16_t));
   double *tab = (double *)malloc(sizeof(double) * (size_t)(taps + 1));
-  if ((!f->fbank && !f->ibank) || !tab) { free(tab); rs_filter_free(f); return -1; }
+  if ((!f->fbank && !f->ibank) || !tab) { free(tab); bl_rs_plan_free(f); return -1; }
 
   const int center = (taps - 1) / 2;
   const int ph_nb = phase_count % 2 ? phase_count : phase_count / 2 + 1;
@@ -200,10 +205,30 @@ static int have_fma3(void) {
 
 static inline int16_t clip16(long v) { return (int16_t)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); }
 
+/* Output n reads the taps that start at ext position w_n = w0 + floor(n * dst_incr /
+ * (src_incr * phase_count)) (ext = taps reflected samples, then the input).  Before the flush
+ * every n with w_n <= frames is produced; the flush appends (min(left, taps) + 1) / 2
+ * reflected samples and the same rule applies once more. */
+size_t bl_rs_out_frames(const bl_rs_plan *f, size_t frames, size_t *refl_out) {
+  const uint64_t L = (uint64_t)f->taps, w0 = L - (L - 1) / 2;
+  if (frames < L + 1) { /* the library waits for taps + 1 samples before it produces any */
+    if (refl_out) *refl_out = 0;
+    return 0;
+  }
+  const uint64_t A = (uint64_t)f->dst_incr, B = (uint64_t)f->src_incr * (uint64_t)f->phase_count;
+  const uint64_t n1 = (((uint64_t)frames - w0 + 1) * B - 1) / A + 1;
+  const uint64_t w1 = w0 + n1 * A / B;
+  const uint64_t left = L + frames - w1;
+  const uint64_t refl = ((left < L ? left : L) + 1) / 2;
+  if (refl_out) *refl_out = (size_t)refl;
+  return (size_t)((((uint64_t)frames + refl - w0 + 1) * B - 1) / A + 1);
+}
+
 /* One channel.  `ext` holds taps mirrored samples, the n input samples, and room for the
  * flush reflection (+ zeroed slack for the padded taps); returns the number of output samples
  * (written to out[0], out[stride], ...). */
-static size_t rs_run(const rs_filter *f, void *ext, int is_float, size_t n, int16_t *out, size_t stride) {
+static size_t rs_run(const bl_rs_plan *f, void *ext, int is_float, size_t n, int16_t *out, size_t stride,
+                     size_t limit) {
   const int L = f->taps, A = f->alloc;
   const int fast = have_fma3();
   float *xf = (float *)ext;
@@ -217,6 +242,7 @@ static size_t rs_run(const rs_filter *f, void *ext, int is_float, size_t n, int1
   int index = 0, frac = 0;
   for (int pass = 0; pass < 2; ++pass) {
     while (w + (size_t)L <= avail) {
+      if (produced >= limit) return limit + 1; /* the closed form and the stepping disagree */
       if (is_float) {
         const float *fr = f->fbank + (size_t)index * A;
         float v;
@@ -261,21 +287,20 @@ int bl_resample_to_stereo_s16(const void *in, int in_is_s32, size_t frames, int 
   *out = NULL;
   *out_frames = 0;
   if (!in || channels < 1 || channels > 2 || in_rate <= 0 || out_rate <= 0) return BL_UNEXPECTED;
-  rs_filter f;
-  if (rs_filter_build(&f, out_rate, in_rate, in_is_s32)) return BL_UNEXPECTED;
+  bl_rs_plan f;
+  if (bl_rs_plan_build(&f, out_rate, in_rate, in_is_s32)) return BL_UNEXPECTED;
   const int L = f.taps;
-  if (frames < (size_t)L + 1) { /* the library waits for taps + 1 samples before it produces any */
-    rs_filter_free(&f);
+  const size_t bound = bl_rs_out_frames(&f, frames, NULL);
+  if (bound == 0) {
+    bl_rs_plan_free(&f);
     return BL_UNEXPECTED;
   }
   const size_t ext_len = (size_t)L + frames + (size_t)L + 32;
   const size_t esz = in_is_s32 ? sizeof(float) : sizeof(int16_t);
   void *ext = calloc(ext_len, esz);
-  if (!ext) { rs_filter_free(&f); return BL_UNEXPECTED; }
-  /* generous bound on the output length */
-  const size_t bound = (size_t)((double)(frames + (size_t)L) * out_rate / in_rate) + 16;
+  if (!ext) { bl_rs_plan_free(&f); return BL_UNEXPECTED; }
   int16_t *o = (int16_t *)malloc(bound * 2 * sizeof(int16_t));
-  if (!o) { free(ext); rs_filter_free(&f); return BL_UNEXPECTED; }
+  if (!o) { free(ext); bl_rs_plan_free(&f); return BL_UNEXPECTED; }
 
   size_t produced = 0;
   for (int c = 0; c < 2; ++c) {
@@ -302,11 +327,11 @@ int bl_resample_to_stereo_s16(const void *in, int in_is_s32, size_t frames, int 
         x[i] = (int16_t)v;
       }
     }
-    produced = rs_run(&f, ext, in_is_s32, frames, o + c, 2);
-    if (produced > bound) { free(o); free(ext); rs_filter_free(&f); return BL_UNEXPECTED; }
+    produced = rs_run(&f, ext, in_is_s32, frames, o + c, 2, bound);
+    if (produced != bound) { free(o); free(ext); bl_rs_plan_free(&f); return BL_UNEXPECTED; }
   }
   free(ext);
-  rs_filter_free(&f);
+  bl_rs_plan_free(&f);
   *out = o;
   *out_frames = produced;
   return BL_OK;

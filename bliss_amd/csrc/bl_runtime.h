@@ -71,6 +71,12 @@ struct bl_amd_ctx {
   bl_buf arena[2];
   hipStream_t streams[2] = {nullptr, nullptr};
   std::vector<void *> registered[2]; /* host ranges pinned in place for wave k */
+  /* device rate converter: the plan of the last (input rate, sample kind) stays uploaded */
+  bl_buf rs_songs, rs_bank;
+  int rs_rate = 0, rs_kind = -1, rs_bank_lds = 0;
+  bl_rs_geom rs_geom{};
+  size_t rs_lds = 0;
+  int rs_taps = 0, rs_phases = 0, rs_src_incr = 0, rs_dst_incr = 0;
 };
 
 /* bl_runtime.hip */

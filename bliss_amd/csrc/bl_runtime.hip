@@ -26,6 +26,7 @@
 #include <thread>
 
 #include "bl_runtime.h"
+#include "bl_resample.h"
 
 namespace {
 
@@ -125,7 +126,7 @@ void ctx_release(bl_amd_ctx *c) {
   (void)hipDeviceSynchronize();
   prof_collect(c);
   bl_buf *bufs[] = {&c->songs,   &c->stats,   &c->hist, &c->spectrum, &c->energies, &c->lc,
-                    &c->results, &c->misc,    &c->arena[0], &c->arena[1]};
+                    &c->results, &c->misc,    &c->arena[0], &c->arena[1], &c->rs_songs, &c->rs_bank};
   for (bl_buf *b : bufs) release_buf(*b);
   for (int k = 0; k < 2; ++k) {
     unregister_wave(c, k);
@@ -149,6 +150,8 @@ void ctx_release(bl_amd_ctx *c) {
   c->side = nullptr;
   c->ev_env = c->ev_tail = c->ev_ws = nullptr;
   c->ws_used = false;
+  c->rs_rate = 0;
+  c->rs_kind = -1;
 }
 
 int current_device(void) {
@@ -751,6 +754,127 @@ int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void
   if (!c) return BL_UNEXPECTED;
   DevGuard dg(c->device);
   return blk_narrow_s32(static_cast<hipStream_t>(stream), d_in, d_out, n, c->n_cu);
+}
+
+/* ---- rate conversion (bl_resample.c on the host, bl_rs_kernels.hip on the device) ---- */
+#define BL_RS_OUT_RATE 22050 /* ref src/decode.c:7 SAMPLE_RATE */
+
+size_t bl_amd_resample_out_frames(size_t frames, int in_rate) {
+  bl_rs_plan p;
+  if (bl_rs_plan_geometry(&p, BL_RS_OUT_RATE, in_rate)) return 0;
+  return bl_rs_out_frames(&p, frames, nullptr);
+}
+
+int bl_amd_resample_host(const void *in, int in_is_s32, size_t frames, int channels, int in_rate,
+                         int16_t **out, size_t *out_frames) {
+  if (!out || !out_frames) return BL_UNEXPECTED;
+  return bl_resample_to_stereo_s16(in, in_is_s32, frames, channels, in_rate, BL_RS_OUT_RATE, out, out_frames);
+}
+
+/* (re)build and upload the plan of (in_rate, kind); caller holds c->mu, device is current */
+static int rs_prepare(bl_amd_ctx *c, int in_rate, int in_is_s32) {
+  if (c->rs_rate == in_rate && c->rs_kind == in_is_s32) return BL_OK;
+  bl_rs_plan p;
+  if (bl_rs_plan_build(&p, BL_RS_OUT_RATE, in_rate, in_is_s32)) {
+    fprintf(stderr, "bliss_amd: no conversion plan for %d Hz\n", in_rate);
+    return BL_UNEXPECTED;
+  }
+  bl_rs_geom g;
+  size_t lds = 0;
+  int bank_lds = 0;
+  if (blk_resample_geom(p.phase_count, p.taps, p.alloc, p.src_incr, p.dst_incr, &g, &lds, &bank_lds) != BL_OK) {
+    fprintf(stderr, "bliss_amd: %d Hz is beyond the device converter (input span of a tile exceeds the LDS)\n",
+            in_rate);
+    bl_rs_plan_free(&p);
+    return BL_UNEXPECTED;
+  }
+  /* 32-bit elements on the device: float as is, Q15 widened */
+  const size_t elems = (size_t)p.phase_count * (size_t)p.alloc;
+  std::vector<int32_t> host(elems);
+  if (in_is_s32) memcpy(host.data(), p.fbank, elems * sizeof(float));
+  else for (size_t i = 0; i < elems; ++i) host[i] = p.ibank[i];
+  bl_rs_plan_free(&p);
+  /* a plan change is rare; kernels of the previous plan may still be reading the old bank */
+  BL_HIP_CHECK(hipDeviceSynchronize());
+  c->rs_rate = 0;
+  c->rs_kind = -1;
+  if (blr_ensure(c->rs_bank, elems * 4) != BL_OK) return BL_UNEXPECTED;
+  BL_HIP_CHECK(hipMemcpy(c->rs_bank.p, host.data(), elems * 4, hipMemcpyHostToDevice));
+  c->rs_geom = g;
+  c->rs_lds = lds;
+  c->rs_bank_lds = bank_lds;
+  c->rs_taps = p.taps;
+  c->rs_phases = p.phase_count;
+  c->rs_src_incr = p.src_incr;
+  c->rs_dst_incr = p.dst_incr;
+  c->rs_rate = in_rate;
+  c->rs_kind = in_is_s32;
+  return BL_OK;
+}
+
+int bl_amd_ctx_resample_batch_device(bl_amd_ctx *c, const void *d_in, int in_is_s32,
+                                     const bl_amd_resample_desc *h_desc, int n_songs, int in_rate,
+                                     int16_t *d_out, void *stream) {
+  if (!c || !d_in || !d_out || !h_desc || n_songs <= 0 || in_rate <= 0) return BL_UNEXPECTED;
+  in_is_s32 = in_is_s32 != 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  if (!dg.ok) return BL_UNEXPECTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rs_prepare(c, in_rate, in_is_s32) != BL_OK) return BL_UNEXPECTED;
+  bl_rs_plan geo;
+  memset(&geo, 0, sizeof geo);
+  geo.taps = c->rs_taps;
+  geo.phase_count = c->rs_phases;
+  geo.src_incr = c->rs_src_incr;
+  geo.dst_incr = c->rs_dst_incr;
+  bl_pin_slot *slot = nullptr;
+  if (ring_get(c, sizeof(bl_rs_dsong) * (size_t)n_songs, &slot) != BL_OK) return BL_UNEXPECTED;
+  bl_rs_dsong *hs = static_cast<bl_rs_dsong *>(slot->p);
+  for (int i = 0; i < n_songs; ++i) {
+    const bl_amd_resample_desc &d = h_desc[i];
+    size_t refl = 0;
+    const size_t of = d.frames > 0 ? bl_rs_out_frames(&geo, (size_t)d.frames, &refl) : 0;
+    if (of == 0 || of > (size_t)INT32_MAX / 2 || (d.channels != 1 && d.channels != 2) ||
+        (d.out_offset & 1) || (d.channels == 2 && (d.in_offset & 1))) {
+      fprintf(stderr,
+              "bliss_amd: resample: song %d rejected (frames=%d channels=%d in_offset=%llu out_offset=%llu): "
+              "need frames > filter length (%d), channels 1|2, even offsets\n",
+              i, d.frames, d.channels, (unsigned long long)d.in_offset, (unsigned long long)d.out_offset,
+              c->rs_taps);
+      return BL_UNEXPECTED;
+    }
+    hs[i].in_off = d.in_offset;
+    hs[i].out_off = d.out_offset;
+    hs[i].frames = d.frames;
+    hs[i].channels = d.channels;
+    hs[i].out_frames = (int)of;
+    hs[i].refl = (int)refl;
+  }
+  if (c->ws_used) BL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ws, 0));
+  if (blr_ensure(c->rs_songs, sizeof(bl_rs_dsong) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
+  bl_rs_dsong *d_songs = static_cast<bl_rs_dsong *>(c->rs_songs.p);
+  BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs, sizeof(bl_rs_dsong) * (size_t)n_songs, hipMemcpyHostToDevice, s));
+  BL_HIP_CHECK(hipEventRecord(slot->ev, s));
+  slot->busy = true;
+  const int G = BL_GROUP_SONGS_MAX;
+  for (int b = 0; b < n_songs; b += G) {
+    const int cnt = std::min(G, n_songs - b);
+    int max_out = 0;
+    for (int i = 0; i < cnt; ++i) max_out = std::max(max_out, hs[b + i].out_frames);
+    if (blk_resample(s, d_in, in_is_s32, d_songs + b, cnt, max_out, c->rs_bank.p, c->rs_geom, c->rs_lds,
+                     c->rs_bank_lds, d_out) != BL_OK)
+      return BL_UNEXPECTED;
+  }
+  BL_HIP_CHECK(hipEventRecord(c->ev_ws, s));
+  c->ws_used = true;
+  return BL_OK;
+}
+
+int bl_amd_resample_batch_device(const void *d_in, int in_is_s32, const bl_amd_resample_desc *h_desc,
+                                 int n_songs, int in_rate, int16_t *d_out, void *stream) {
+  return bl_amd_ctx_resample_batch_device(blr_default_ctx(), d_in, in_is_s32, h_desc, n_songs, in_rate,
+                                          d_out, stream);
 }
 
 /* ---- helpers behind the reference-API shims of bl_api.c ---- */

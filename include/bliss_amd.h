@@ -113,6 +113,34 @@ int bl_amd_analyze_batch_host_s32(const int32_t *const *h_pcm, const int32_t *n_
 /* The same narrowing for a device-resident int32 buffer: d_out[i] = (int16)(d_in[i] >> 16). */
 int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void *stream);
 
+/* Rate conversion to the analyzers' 22 050 Hz stereo s16 — the arithmetic bl_audio_decode()
+ * applies to a file at another rate (a restatement of libswresample's default resampler that
+ * reproduces the digests of ref tests/test_decode.c:35-36,55-56), for
+ * callers that bring their own decoder.  `in`: interleaved frames of 1 or 2 channels at in_rate
+ * Hz, int16, or (in_is_s32) int32 left-justified.  A mono source comes out as two equal
+ * channels at gain 1/sqrt(2), as the reference's out layout does.
+ *   bl_amd_resample_out_frames: output frames for `frames` of input (0: shorter than the filter);
+ *   bl_amd_resample_host: *out is malloc'd (free() it), 2 * *out_frames int16;
+ *   bl_amd_resample_batch_device: songs resident in HBM, one call for the batch; song i reads
+ *     h_desc[i].frames frames at d_in + in_offset (elements of the input type) and writes
+ *     2 * bl_amd_resample_out_frames(frames, in_rate) int16 at d_out + out_offset, which is what
+ *     bl_amd_analyze_batch_device takes (pcm_offset = out_offset, n_samples = 2 * out frames).
+ *     Asynchronous on `stream`; bit-identical to the host form. */
+typedef struct bl_amd_resample_desc {
+  uint64_t in_offset;  /* elements from d_in; even for stereo */
+  uint64_t out_offset; /* int16 elements from d_out; even (multiple of 8 to feed the analysis) */
+  int32_t frames;      /* input frames */
+  int32_t channels;    /* 1 or 2 */
+} bl_amd_resample_desc;
+size_t bl_amd_resample_out_frames(size_t frames, int in_rate);
+int bl_amd_resample_host(const void *in, int in_is_s32, size_t frames, int channels, int in_rate,
+                         int16_t **out, size_t *out_frames);
+int bl_amd_resample_batch_device(const void *d_in, int in_is_s32, const bl_amd_resample_desc *h_desc,
+                                 int n_songs, int in_rate, int16_t *d_out, void *stream);
+int bl_amd_ctx_resample_batch_device(bl_amd_ctx *ctx, const void *d_in, int in_is_s32,
+                                     const bl_amd_resample_desc *h_desc, int n_songs, int in_rate,
+                                     int16_t *d_out, void *stream);
+
 /* Batch-of-songs mode across the GPUs of one node (BASELINE configs[2]): the corpus is
  * sharded by song over the ranks listed in `devices` (one host thread and one context per
  * rank: contiguous blocks for equal lengths, longest-first greedy by sample count
