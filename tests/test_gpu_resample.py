@@ -51,6 +51,7 @@ def _device_convert(songs, channels, rate):
     (48000, "s16"), (48000, "s32"),       # 147 phases, bank in LDS
     (32000, "s32"), (96000, "s16"),       # 441 / 147 phases, longer filters
     (8000, "s16"), (11025, "s32"),        # up-sampling (factor 1, 32 taps)
+    (88200, "s16"), (88200, "s32"),       # one phase, step 4, 132 taps
     (192000, "s32"), (176400, "s16"),     # bank too large for the LDS: read through L1/L2
 ])
 def test_device_equals_host_bit_for_bit(gpu_lib, rate, kind):

@@ -23,7 +23,7 @@ def main():
     lib = bliss_amd.load()
     assert lib.bl_amd_init(0) == 0
     rows = []
-    for rate, kind in ((44100, "s16"), (48000, "s16"), (44100, "s32"), (48000, "s32"), (96000, "s32")):
+    for rate, kind in ((44100, "s16"), (48000, "s16"), (44100, "s32"), (48000, "s32"), (88200, "s16"), (88200, "s32"), (96000, "s32")):
         frames = rate * args.seconds
         dt = torch.int16 if kind == "s16" else torch.int32
         per_song = (2 * frames + 7) & ~7
