@@ -9,11 +9,19 @@
  * the Q15 bank and a wrapping 32-bit accumulator; wider sources use float with the eight
  * strided partial sums of fused multiply-adds combined pairwise, then rint(v * 32768) clipped.
  *
- * One workgroup converts RS_TILE consecutive output frames of one song.  It stages the input
- * span those outputs read (reflected at the song's edges exactly as the host form does) and,
- * when it fits, the bank into LDS; then each lane computes one output frame at a time.  The
- * work is LDS-read bound (taps * (1 coefficient + channels samples) reads per output frame);
- * bank rows are padded to an odd stride so that lanes on different phases spread over the banks.
+ * Three kernels, chosen by the plan (blk_resample):
+ *   k_resample_1p  one phase and a whole-number step — 44.1 kHz (and 88.2 kHz): the taps sit in
+ *                  scalar registers, a lane computes four consecutive outputs from one pass over
+ *                  the frames they share;
+ *   k_resample_pm  many phases whose cycle advances a whole number of input frames — 48 kHz: a
+ *                  wave takes one phase at a time (taps wave-uniform), its lanes outputs one
+ *                  cycle apart, the next tile's input is fetched while one is computed;
+ *   k_resample     everything else (other rates, up-sampling): one workgroup converts RS_TILE
+ *                  consecutive output frames; it stages the input span those outputs read and,
+ *                  when it fits, the bank into LDS (rows padded to an odd stride so that lanes
+ *                  on different phases spread over the banks), one output frame per lane at a
+ *                  time — LDS-read bound, taps * (1 coefficient + channels samples) reads per frame.
+ * All three reflect the input at the song's edges exactly as the host form does.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -225,10 +233,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
       const int4 *src = reinterpret_cast<const int4 *>(p + 2 * x_first);
       int4 v[PER];
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int idx = tid + RS_THREADS * i;
-        if (idx < NV) v[i] = src[idx];
-      }
+      for (int i = 0; i < PER; ++i) v[i] = src[min(tid + RS_THREADS * i, NV - 1)]; /* clamped, not masked */
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int idx = tid + RS_THREADS * i, k = 2 * idx;
@@ -267,10 +272,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
       const uint4 *src = reinterpret_cast<const uint4 *>(p + 2 * x_first);
       uint4 v[PER];
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int idx = tid + RS_THREADS * i;
-        if (idx < NV) v[i] = src[idx];
-      }
+      for (int i = 0; i < PER; ++i) v[i] = src[min(tid + RS_THREADS * i, NV - 1)]; /* clamped, not masked */
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int idx = tid + RS_THREADS * i;
@@ -408,9 +410,6 @@ int rs_launch_1p(hipStream_t s, const void *d_in, const bl_rs_dsong *d_songs, in
  * into int16 pairs on the scalar unit — shifted by one tap when the window starts on an odd
  * frame.  float: one channel per pass (a stereo tile does not fit the LDS), eight partial sums in
  * the host's order.  Results go through an LDS tile so that the stores to HBM are contiguous. */
-#ifndef RSP_DBG
-#define RSP_DBG 0
-#endif
 #define RSP_WAVES 8
 #define RSP_THREADS (64 * RSP_WAVES)
 
@@ -482,8 +481,8 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
         const int m = wave + RSP_WAVES * k;
 #pragma unroll
         for (int u = 0; u < PFU; ++u) {
-          const int q = lane + 64 * u;
-          if (q < nq) pf[k][u] = src[(m * adv) / 4 + q];
+          /* unconditional (clamped): a load under a lane mask makes the compiler wait for it at once */
+          pf[k][u] = src[(m * adv) / 4 + min(lane + 64 * u, nq - 1)];
         }
       }
     };
@@ -541,15 +540,12 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
     bool fetched = interior(tile_begin);
     if (fetched) prefetch(tile_begin);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-#if RSP_DBG != 2
       if (fetched) commit();
       else stage_slow(tile);
-#endif
       __syncthreads();
       fetched = tile + 1 < tile_end && interior(tile + 1);
       if (fetched) prefetch(tile + 1);
 
-#if RSP_DBG != 1
       int base = base0, idx = idx0;
       for (int r = wave; r < pc; r += RSP_WAVES) {
         /* lane j takes the phase's j-th pair of taps from the table; v_readlane hands it to
@@ -579,7 +575,6 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
         base += base_step;
         if (idx >= pc) { idx -= pc; ++base; }
       }
-#endif
       __syncthreads();
       const long long n0 = (long long)tile * T;
       const int cnt = (int)min((long long)T, (long long)sg.out_frames - n0);
@@ -594,6 +589,34 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
       const long long xf = x_first_of(tile);
       for (int ch = 0; ch < (stereo ? 2 : 1); ++ch) {
         __syncthreads(); /* every wave is done with the previous samples and output tile */
+        const int nu = (rfr + 1) / 2; /* 16-byte units (2 frames, both channels) per region */
+        const bool fast = stereo && ((reinterpret_cast<size_t>(p) & 15) == 0) && xf >= 0 &&
+                          xf + 63LL * adv + 2LL * nu <= N && nu <= 256;
+        if (fast) { /* away from the song's edges: 16-byte loads, 16 in flight per lane */
+          const int4 *src = reinterpret_cast<const int4 *>(p + 2 * xf);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            int4 v[RSP_REG / 2][4];
+#pragma unroll
+            for (int k = 0; k < RSP_REG / 2; ++k) {
+              const int m = wave + RSP_WAVES * (half * (RSP_REG / 2) + k);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) v[k][u] = src[(m * adv) / 2 + min(lane + 64 * u, nu - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < RSP_REG / 2; ++k) {
+              const int m = wave + RSP_WAVES * (half * (RSP_REG / 2) + k);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int q = lane + 64 * u;
+                if (q < nu) {
+                  xs[m * R + 2 * q] = (float)(ch ? v[k][u].y : v[k][u].x) * (1.0f / 2147483648.0f);
+                  xs[m * R + 2 * q + 1] = (float)(ch ? v[k][u].w : v[k][u].z) * (1.0f / 2147483648.0f);
+                }
+              }
+            }
+          }
+        } else
         for (int m = wave; m < 64; m += RSP_WAVES) {
           for (int j0 = 0; j0 < rfr; j0 += 256) {
             float v[4];
@@ -746,7 +769,7 @@ int blk_resample(hipStream_t s, const void *d_in, int in_is_s32, const bl_rs_dso
     P.w0 = g.w0;
     P.row_stride = g.alloc;
     const int rfr = (int)adv + g.taps + 4; /* + the alignment lead, see the kernel */
-    P.rstride = in_is_s32 ? (rfr | 1) : ((rfr / 2 + 1) | 1);
+    P.rstride = in_is_s32 ? ((rfr + 2) | 1) : ((rfr / 2 + 1) | 1);
     const size_t lds = ((size_t)g.phase_count * 64 + (size_t)(in_is_s32 ? 1 : 2) * 64 * (size_t)P.rstride +
                         (in_is_s32 ? 0 : (size_t)g.phase_count * (g.taps / 2 + 1))) * 4;
     /* a workgroup walks a run of tiles (the next one is fetched while one is computed); short
