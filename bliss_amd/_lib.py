@@ -87,6 +87,8 @@ SYMBOLS = {
     "bl_amd_set_host_transfer": (C.c_int, [C.c_int]),
     "bl_amd_analyze_batch_host_s32": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
                                                 _P(C.c_uint64), C.c_int, _P(SongResult)]),
+    "bl_amd_analyze_batch_host_rate": (C.c_int, [_P(C.c_void_p), C.c_int, _P(C.c_int32), _P(C.c_int32),
+                                                 _P(C.c_uint64), C.c_int, C.c_int, _P(SongResult)]),
     "bl_amd_narrow_s32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bl_amd_resample_out_frames": (C.c_size_t, [C.c_size_t, C.c_int]),
     "bl_amd_resample_host": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,

@@ -166,6 +166,19 @@ def analyze_batch_host_s32(pcm_list, channels, durations):
     return results_to_numpy(bytes(out))
 
 
+def analyze_batch_host_rate(pcm_list, channels, durations, sample_rate):
+    """Songs at `sample_rate` Hz (1-D int16 or int32 arrays, all of one dtype): each wave is
+    converted to 22 050 Hz stereo on the device between its transfer and its analysis."""
+    lib = _lib.load()
+    dtype = np.asarray(pcm_list[0]).dtype
+    if dtype not in (np.int16, np.int32):
+        raise TypeError("int16 or int32 PCM expected")
+    (ptrs, ns, chs, dus, n), out, _keep = _host_args(pcm_list, channels, durations, dtype)
+    _check(lib.bl_amd_analyze_batch_host_rate(ptrs, int(dtype == np.int32), ns, chs, dus, n, int(sample_rate), out),
+           "bl_amd_analyze_batch_host_rate")
+    return results_to_numpy(bytes(out))
+
+
 def analyze_corpus_multi(pcm_list, channels, durations, devices, gather="rccl", matrix=True):
     """Shard the corpus over `devices` (a rank per entry), analyse, all-gather the force vectors
     and compute the bl_distance matrix by row blocks (bl_amd_analyze_corpus_multi).  Returns

@@ -134,7 +134,7 @@ void rank_main(RankJob j) {
   std::unique_lock<std::mutex> lk(j.ctx->mu);
   bl_amd_song_result *d_res = nullptr;
   if (ok && cnt > 0)
-    ok = blr_analyze_host(j.ctx, pcm.data(), 0, ns.data(), ch.data(), du.data(), cnt, res.data(), &d_res) == BL_OK;
+    ok = blr_analyze_host(j.ctx, pcm.data(), 0, ns.data(), ch.data(), du.data(), cnt, 0, res.data(), &d_res) == BL_OK;
   if (ok)
     for (int i = 0; i < cnt; ++i) j.h_results[(*j.mine)[i]] = res[i];
 

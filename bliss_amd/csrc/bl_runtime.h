@@ -69,6 +69,7 @@ struct bl_amd_ctx {
   void *pinned[2] = {nullptr, nullptr};
   size_t pinned_cap[2] = {0, 0};
   bl_buf arena[2];
+  bl_buf arena22[2]; /* converted (22 050 Hz) songs of a wave whose input is at another rate */
   hipStream_t streams[2] = {nullptr, nullptr};
   std::vector<void *> registered[2]; /* host ranges pinned in place for wave k */
   /* device rate converter: the plan of the last (input rate, sample kind) stays uploaded */
@@ -86,10 +87,11 @@ bl_amd_ctx *blr_default_ctx(void);
 int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
                        bl_amd_song_result *d_results, hipStream_t stream, int what);
 /* host-memory batch on one context; pcm_is_s32: h_pcm[i] points at int32 samples that are
- * narrowed with >> 16 while they are staged.  d_res_out (optional) receives the device
+ * narrowed with >> 16 while they are staged.  in_rate: 0 / 22 050 = as is; another rate = the songs
+ * are converted on the device first (wide sources then travel as int32).  d_res_out (optional) receives the device
  * pointer of the results (valid until the context's next host batch). */
 int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, const int32_t *n_samples,
-                     const int32_t *channels, const uint64_t *duration, int n_songs,
+                     const int32_t *channels, const uint64_t *duration, int n_songs, int in_rate,
                      bl_amd_song_result *h_results, bl_amd_song_result **d_res_out);
 
 #endif /* BL_RUNTIME_H_ */

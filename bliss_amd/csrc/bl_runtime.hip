@@ -126,7 +126,8 @@ void ctx_release(bl_amd_ctx *c) {
   (void)hipDeviceSynchronize();
   prof_collect(c);
   bl_buf *bufs[] = {&c->songs,   &c->stats,   &c->hist, &c->spectrum, &c->energies, &c->lc,
-                    &c->results, &c->misc,    &c->arena[0], &c->arena[1], &c->rs_songs, &c->rs_bank};
+                    &c->results, &c->misc,    &c->arena[0], &c->arena[1], &c->arena22[0], &c->arena22[1],
+                    &c->rs_songs, &c->rs_bank};
   for (bl_buf *b : bufs) release_buf(*b);
   for (int k = 0; k < 2; ++k) {
     unregister_wave(c, k);
@@ -345,6 +346,106 @@ int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_de
   return BL_OK;
 }
 
+/* ---- device rate conversion (bl_rs_kernels.hip), shared by the C-ABI and the host batch ---- */
+#define BL_RS_OUT_RATE 22050 /* ref src/decode.c:7 SAMPLE_RATE */
+
+/* (re)build and upload the plan of (in_rate, kind); caller holds c->mu, device is current */
+static int rs_prepare(bl_amd_ctx *c, int in_rate, int in_is_s32) {
+  if (c->rs_rate == in_rate && c->rs_kind == in_is_s32) return BL_OK;
+  bl_rs_plan p;
+  if (bl_rs_plan_build(&p, BL_RS_OUT_RATE, in_rate, in_is_s32)) {
+    fprintf(stderr, "bliss_amd: no conversion plan for %d Hz\n", in_rate);
+    return BL_UNEXPECTED;
+  }
+  bl_rs_geom g;
+  size_t lds = 0;
+  int bank_lds = 0;
+  if (blk_resample_geom(p.phase_count, p.taps, p.alloc, p.src_incr, p.dst_incr, &g, &lds, &bank_lds) != BL_OK) {
+    fprintf(stderr, "bliss_amd: %d Hz is beyond the device converter (input span of a tile exceeds the LDS)\n",
+            in_rate);
+    bl_rs_plan_free(&p);
+    return BL_UNEXPECTED;
+  }
+  /* 32-bit elements on the device: float as is, Q15 widened */
+  const size_t elems = (size_t)p.phase_count * (size_t)p.alloc;
+  std::vector<int32_t> host(elems);
+  if (in_is_s32) memcpy(host.data(), p.fbank, elems * sizeof(float));
+  else for (size_t i = 0; i < elems; ++i) host[i] = p.ibank[i];
+  bl_rs_plan_free(&p);
+  /* a plan change is rare; kernels of the previous plan may still be reading the old bank */
+  BL_HIP_CHECK(hipDeviceSynchronize());
+  c->rs_rate = 0;
+  c->rs_kind = -1;
+  if (blr_ensure(c->rs_bank, elems * 4) != BL_OK) return BL_UNEXPECTED;
+  BL_HIP_CHECK(hipMemcpy(c->rs_bank.p, host.data(), elems * 4, hipMemcpyHostToDevice));
+  c->rs_geom = g;
+  c->rs_lds = lds;
+  c->rs_bank_lds = bank_lds;
+  c->rs_taps = p.taps;
+  c->rs_phases = p.phase_count;
+  c->rs_src_incr = p.src_incr;
+  c->rs_dst_incr = p.dst_incr;
+  c->rs_rate = in_rate;
+  c->rs_kind = in_is_s32;
+  return BL_OK;
+}
+
+/* Enqueue the conversion of n_songs device-resident songs on `s` (caller holds c->mu and has
+ * made c->device current). */
+int blr_resample_device(bl_amd_ctx *c, const void *d_in, int in_is_s32, const bl_amd_resample_desc *h_desc,
+                        int n_songs, int in_rate, int16_t *d_out, hipStream_t s) {
+  in_is_s32 = in_is_s32 != 0;
+  if (rs_prepare(c, in_rate, in_is_s32) != BL_OK) return BL_UNEXPECTED;
+  bl_rs_plan geo;
+  memset(&geo, 0, sizeof geo);
+  geo.taps = c->rs_taps;
+  geo.phase_count = c->rs_phases;
+  geo.src_incr = c->rs_src_incr;
+  geo.dst_incr = c->rs_dst_incr;
+  bl_pin_slot *slot = nullptr;
+  if (ring_get(c, sizeof(bl_rs_dsong) * (size_t)n_songs, &slot) != BL_OK) return BL_UNEXPECTED;
+  bl_rs_dsong *hs = static_cast<bl_rs_dsong *>(slot->p);
+  for (int i = 0; i < n_songs; ++i) {
+    const bl_amd_resample_desc &d = h_desc[i];
+    size_t refl = 0;
+    const size_t of = d.frames > 0 ? bl_rs_out_frames(&geo, (size_t)d.frames, &refl) : 0;
+    if (of == 0 || of > (size_t)INT32_MAX / 2 || (d.channels != 1 && d.channels != 2) ||
+        (d.out_offset & 1) || (d.channels == 2 && (d.in_offset & 1))) {
+      fprintf(stderr,
+              "bliss_amd: resample: song %d rejected (frames=%d channels=%d in_offset=%llu out_offset=%llu): "
+              "need frames > filter length (%d), channels 1|2, even offsets\n",
+              i, d.frames, d.channels, (unsigned long long)d.in_offset, (unsigned long long)d.out_offset,
+              c->rs_taps);
+      return BL_UNEXPECTED;
+    }
+    hs[i].in_off = d.in_offset;
+    hs[i].out_off = d.out_offset;
+    hs[i].frames = d.frames;
+    hs[i].channels = d.channels;
+    hs[i].out_frames = (int)of;
+    hs[i].refl = (int)refl;
+  }
+  if (c->ws_used) BL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ws, 0));
+  if (blr_ensure(c->rs_songs, sizeof(bl_rs_dsong) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
+  bl_rs_dsong *d_songs = static_cast<bl_rs_dsong *>(c->rs_songs.p);
+  BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs, sizeof(bl_rs_dsong) * (size_t)n_songs, hipMemcpyHostToDevice, s));
+  BL_HIP_CHECK(hipEventRecord(slot->ev, s));
+  slot->busy = true;
+  const int G = BL_GROUP_SONGS_MAX;
+  for (int b = 0; b < n_songs; b += G) {
+    const int cnt = std::min(G, n_songs - b);
+    int max_out = 0;
+    for (int i = 0; i < cnt; ++i) max_out = std::max(max_out, hs[b + i].out_frames);
+    if (blk_resample(s, d_in, in_is_s32, d_songs + b, cnt, max_out, c->rs_bank.p, c->rs_geom, c->rs_lds,
+                     c->rs_bank_lds, d_out) != BL_OK)
+      return BL_UNEXPECTED;
+  }
+  BL_HIP_CHECK(hipEventRecord(c->ev_ws, s));
+  c->ws_used = true;
+  return BL_OK;
+}
+
+
 /* ---- host-memory batch: pinned staging, copy/compute overlap on 2 streams ---- */
 #ifndef BL_STAGE_THREADS
 #define BL_STAGE_THREADS 8 /* host threads of the staging copy (BL_AMD_STAGE_THREADS overrides) */
@@ -371,8 +472,16 @@ static int host_mode(void) {
 }
 
 int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, const int32_t *n_samples,
-                     const int32_t *channels, const uint64_t *duration, int n_songs,
+                     const int32_t *channels, const uint64_t *duration, int n_songs, int in_rate,
                      bl_amd_song_result *h_results, bl_amd_song_result **d_res_out) {
+  /* songs at another rate than the analyzers' are converted on the device, wave by wave, between
+   * the transfer and the analysis; wide sources then travel as int32 (the converter's float path
+   * needs all their bits) */
+  const bool convert = in_rate > 0 && in_rate != BL_RS_OUT_RATE;
+  bl_rs_plan geo;
+  memset(&geo, 0, sizeof geo);
+  if (convert && bl_rs_plan_geometry(&geo, BL_RS_OUT_RATE, in_rate)) return BL_UNEXPECTED;
+  const size_t esz = (convert && pcm_is_s32) ? 4 : 2; /* bytes per staged sample */
   /* reject bad descriptors before anything is staged (a negative length would otherwise
    * become a ~2^64-byte copy) */
   for (int i = 0; i < n_songs; ++i) {
@@ -382,13 +491,22 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
     }
     bl_amd_song_desc d;
     d.pcm_offset = 0; d.n_samples = n_samples[i]; d.channels = channels[i]; d.duration = duration[i];
+    if (convert) { /* what the analyzers will see: stereo at 22 050 Hz */
+      if (n_samples[i] <= 0 || (channels[i] != 1 && channels[i] != 2) || n_samples[i] % channels[i]) {
+        fprintf(stderr, "bliss_amd: song %d rejected (n_samples=%d channels=%d)\n", i, n_samples[i], channels[i]);
+        return BL_UNEXPECTED;
+      }
+      const size_t of = bl_rs_out_frames(&geo, (size_t)(n_samples[i] / channels[i]), nullptr);
+      d.n_samples = of > (size_t)INT32_MAX / 2 ? -1 : (int32_t)(2 * of);
+      d.channels = 2;
+    }
     if (validate_desc(d, i) != BL_OK) return BL_UNEXPECTED;
   }
   for (int k = 0; k < 2; ++k)
     if (!c->streams[k]) BL_HIP_CHECK(hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking));
   if (blr_ensure(c->results, sizeof(bl_amd_song_result) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
   bl_amd_song_result *d_res = static_cast<bl_amd_song_result *>(c->results.p);
-  const bool in_place = !pcm_is_s32 && host_mode() == BL_AMD_HOST_REGISTERED;
+  const bool in_place = esz == 2 && !pcm_is_s32 && host_mode() == BL_AMD_HOST_REGISTERED;
 
   /* waves of songs of at most WAVE_BYTES of PCM each (one song may exceed it): large enough
    * that the ~20 ms latency of the serial envelope tail (paid once per wave) stays below
@@ -406,20 +524,33 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
   bool used[2] = {false, false};
   while (begin < n_songs && rc == BL_OK) {
     const int k = wave & 1;
-    size_t elems = 0;
+    size_t elems = 0, elems22 = 0;
     int end = begin;
-    std::vector<bl_amd_song_desc> desc;
+    std::vector<bl_amd_song_desc> desc;   /* the staged songs (native rate when converting) */
+    std::vector<bl_amd_song_desc> desc22; /* converting: the songs as the analysis sees them */
+    std::vector<bl_amd_resample_desc> rdesc;
     while (end < n_songs) {
       const size_t need = ((size_t)n_samples[end] + 7) & ~(size_t)7;
-      if (end > begin && (elems + need) * 2 > WAVE_BYTES) break;
+      if (end > begin && (elems + need) * esz > WAVE_BYTES) break;
       bl_amd_song_desc d;
       d.pcm_offset = elems; d.n_samples = n_samples[end]; d.channels = channels[end];
       d.duration = duration[end];
       desc.push_back(d);
+      if (convert) {
+        const size_t frames = (size_t)(n_samples[end] / channels[end]);
+        const size_t of = bl_rs_out_frames(&geo, frames, nullptr);
+        bl_amd_resample_desc r;
+        r.in_offset = elems; r.out_offset = elems22; r.frames = (int32_t)frames; r.channels = channels[end];
+        rdesc.push_back(r);
+        bl_amd_song_desc d2;
+        d2.pcm_offset = elems22; d2.n_samples = (int32_t)(2 * of); d2.channels = 2; d2.duration = duration[end];
+        desc22.push_back(d2);
+        elems22 += (2 * of + 7) & ~(size_t)7;
+      }
       elems += need;
       ++end;
     }
-    const size_t bytes = elems * 2 + 64;
+    const size_t bytes = elems * esz + 64;
     const bool trace = getenv("BL_AMD_HOST_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = now();
@@ -450,21 +581,26 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
         if (hipHostMalloc(&c->pinned[k], bytes, hipHostMallocDefault) != hipSuccess) { rc = BL_UNEXPECTED; break; }
         c->pinned_cap[k] = bytes;
       }
-      int16_t *stage = static_cast<int16_t *>(c->pinned[k]);
+      unsigned char *stage = static_cast<unsigned char *>(c->pinned[k]);
       /* staging copy on several host threads: one thread moves ~10 GB/s, the link takes more.
        * 32-bit sources are narrowed here (>> 16), so the link only ever carries s16. */
-      const int n_thr = (int)std::min<size_t>((size_t)stage_threads(), std::max<size_t>(1, elems * 2 / ((size_t)32 << 20)));
+      const int n_thr = (int)std::min<size_t>((size_t)stage_threads(), std::max<size_t>(1, elems * esz / ((size_t)32 << 20)));
       auto copy_range = [&](int t) {
         for (size_t i = (size_t)t; i < desc.size(); i += (size_t)n_thr) {
-          int16_t *dst = stage + desc[i].pcm_offset;
-          const size_t n = (size_t)desc[i].n_samples;
+          const size_t n = (size_t)desc[i].n_samples, padded = (n + 7) & ~(size_t)7;
+          if (esz == 4) { /* wide source on its way to the converter: all 32 bits */
+            int32_t *dst = reinterpret_cast<int32_t *>(stage) + desc[i].pcm_offset;
+            memcpy(dst, h_pcm[begin + i], n * 4);
+            for (size_t z = n; z < padded; ++z) dst[z] = 0;
+            continue;
+          }
+          int16_t *dst = reinterpret_cast<int16_t *>(stage) + desc[i].pcm_offset;
           if (pcm_is_s32) {
             const int32_t *src = static_cast<const int32_t *>(h_pcm[begin + i]);
             for (size_t j = 0; j < n; ++j) dst[j] = (int16_t)(src[j] >> 16);
           } else {
             memcpy(dst, h_pcm[begin + i], n * 2);
           }
-          const size_t padded = (n + 7) & ~(size_t)7;
           for (size_t z = n; z < padded; ++z) dst[z] = 0;
         }
       };
@@ -473,11 +609,23 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
       copy_range(0);
       for (auto &th : pool) th.join();
       if (trace) fprintf(stderr, "wave %d: wait %.1f ms, stage copy %.1f ms (%zu MB, %d threads)\n", wave,
-                         1e3 * (t_b - t_a), 1e3 * (now() - t_b), elems * 2 >> 20, n_thr);
-      if (hipMemcpyAsync(d_arena, stage, elems * 2, hipMemcpyHostToDevice, s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
+                         1e3 * (t_b - t_a), 1e3 * (now() - t_b), elems * esz >> 20, n_thr);
+      if (hipMemcpyAsync(d_arena, stage, elems * esz, hipMemcpyHostToDevice, s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
     }
     if (hipEventRecord(done[k], s) != hipSuccess) { rc = BL_UNEXPECTED; break; }
-    if (blr_analyze_device(c, d_arena, desc.data(), (int)desc.size(), d_res + begin, s, 7) != BL_OK) {
+    const int16_t *d_pcm = d_arena;
+    const bl_amd_song_desc *wave_desc = desc.data();
+    if (convert) { /* native-rate arena -> 22 050 Hz arena of the same wave slot, same stream */
+      if (blr_ensure(c->arena22[k], elems22 * 2 + 64) != BL_OK) { rc = BL_UNEXPECTED; break; }
+      int16_t *d22 = static_cast<int16_t *>(c->arena22[k].p);
+      if (blr_resample_device(c, d_arena, esz == 4, rdesc.data(), (int)rdesc.size(), in_rate, d22, s) != BL_OK) {
+        rc = BL_UNEXPECTED;
+        break;
+      }
+      d_pcm = d22;
+      wave_desc = desc22.data();
+    }
+    if (blr_analyze_device(c, d_pcm, wave_desc, (int)desc.size(), d_res + begin, s, 7) != BL_OK) {
       rc = BL_UNEXPECTED;
       break;
     }
@@ -725,7 +873,7 @@ int bl_amd_ctx_analyze_batch_host(bl_amd_ctx *ctx, const int16_t *const *h_pcm, 
   DevGuard dg(ctx->device);
   if (!dg.ok) return BL_UNEXPECTED;
   return blr_analyze_host(ctx, reinterpret_cast<const void *const *>(h_pcm), 0, n_samples, channels,
-                          duration, n_songs, h_results, nullptr);
+                          duration, n_songs, 0, h_results, nullptr);
 }
 
 int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samples,
@@ -744,7 +892,21 @@ int bl_amd_analyze_batch_host_s32(const int32_t *const *h_pcm, const int32_t *n_
   std::lock_guard<std::mutex> lk(c->mu);
   DevGuard dg(c->device);
   return blr_analyze_host(c, reinterpret_cast<const void *const *>(h_pcm), 1, n_samples, channels,
-                          duration, n_songs, h_results, nullptr);
+                          duration, n_songs, 0, h_results, nullptr);
+}
+
+int bl_amd_analyze_batch_host_rate(const void *const *h_pcm, int pcm_is_s32, const int32_t *n_samples,
+                                   const int32_t *channels, const uint64_t *duration, int n_songs,
+                                   int sample_rate, bl_amd_song_result *h_results) {
+  if (n_songs <= 0 || !h_pcm || !n_samples || !channels || !duration || !h_results || sample_rate <= 0)
+    return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DevGuard dg(c->device);
+  if (!dg.ok) return BL_UNEXPECTED;
+  return blr_analyze_host(c, h_pcm, pcm_is_s32 != 0, n_samples, channels, duration, n_songs, sample_rate,
+                          h_results, nullptr);
 }
 
 int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void *stream) {
@@ -757,7 +919,6 @@ int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void
 }
 
 /* ---- rate conversion (bl_resample.c on the host, bl_rs_kernels.hip on the device) ---- */
-#define BL_RS_OUT_RATE 22050 /* ref src/decode.c:7 SAMPLE_RATE */
 
 size_t bl_amd_resample_out_frames(size_t frames, int in_rate) {
   bl_rs_plan p;
@@ -771,104 +932,14 @@ int bl_amd_resample_host(const void *in, int in_is_s32, size_t frames, int chann
   return bl_resample_to_stereo_s16(in, in_is_s32, frames, channels, in_rate, BL_RS_OUT_RATE, out, out_frames);
 }
 
-/* (re)build and upload the plan of (in_rate, kind); caller holds c->mu, device is current */
-static int rs_prepare(bl_amd_ctx *c, int in_rate, int in_is_s32) {
-  if (c->rs_rate == in_rate && c->rs_kind == in_is_s32) return BL_OK;
-  bl_rs_plan p;
-  if (bl_rs_plan_build(&p, BL_RS_OUT_RATE, in_rate, in_is_s32)) {
-    fprintf(stderr, "bliss_amd: no conversion plan for %d Hz\n", in_rate);
-    return BL_UNEXPECTED;
-  }
-  bl_rs_geom g;
-  size_t lds = 0;
-  int bank_lds = 0;
-  if (blk_resample_geom(p.phase_count, p.taps, p.alloc, p.src_incr, p.dst_incr, &g, &lds, &bank_lds) != BL_OK) {
-    fprintf(stderr, "bliss_amd: %d Hz is beyond the device converter (input span of a tile exceeds the LDS)\n",
-            in_rate);
-    bl_rs_plan_free(&p);
-    return BL_UNEXPECTED;
-  }
-  /* 32-bit elements on the device: float as is, Q15 widened */
-  const size_t elems = (size_t)p.phase_count * (size_t)p.alloc;
-  std::vector<int32_t> host(elems);
-  if (in_is_s32) memcpy(host.data(), p.fbank, elems * sizeof(float));
-  else for (size_t i = 0; i < elems; ++i) host[i] = p.ibank[i];
-  bl_rs_plan_free(&p);
-  /* a plan change is rare; kernels of the previous plan may still be reading the old bank */
-  BL_HIP_CHECK(hipDeviceSynchronize());
-  c->rs_rate = 0;
-  c->rs_kind = -1;
-  if (blr_ensure(c->rs_bank, elems * 4) != BL_OK) return BL_UNEXPECTED;
-  BL_HIP_CHECK(hipMemcpy(c->rs_bank.p, host.data(), elems * 4, hipMemcpyHostToDevice));
-  c->rs_geom = g;
-  c->rs_lds = lds;
-  c->rs_bank_lds = bank_lds;
-  c->rs_taps = p.taps;
-  c->rs_phases = p.phase_count;
-  c->rs_src_incr = p.src_incr;
-  c->rs_dst_incr = p.dst_incr;
-  c->rs_rate = in_rate;
-  c->rs_kind = in_is_s32;
-  return BL_OK;
-}
-
 int bl_amd_ctx_resample_batch_device(bl_amd_ctx *c, const void *d_in, int in_is_s32,
                                      const bl_amd_resample_desc *h_desc, int n_songs, int in_rate,
                                      int16_t *d_out, void *stream) {
   if (!c || !d_in || !d_out || !h_desc || n_songs <= 0 || in_rate <= 0) return BL_UNEXPECTED;
-  in_is_s32 = in_is_s32 != 0;
   std::lock_guard<std::mutex> lk(c->mu);
   DevGuard dg(c->device);
   if (!dg.ok) return BL_UNEXPECTED;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (rs_prepare(c, in_rate, in_is_s32) != BL_OK) return BL_UNEXPECTED;
-  bl_rs_plan geo;
-  memset(&geo, 0, sizeof geo);
-  geo.taps = c->rs_taps;
-  geo.phase_count = c->rs_phases;
-  geo.src_incr = c->rs_src_incr;
-  geo.dst_incr = c->rs_dst_incr;
-  bl_pin_slot *slot = nullptr;
-  if (ring_get(c, sizeof(bl_rs_dsong) * (size_t)n_songs, &slot) != BL_OK) return BL_UNEXPECTED;
-  bl_rs_dsong *hs = static_cast<bl_rs_dsong *>(slot->p);
-  for (int i = 0; i < n_songs; ++i) {
-    const bl_amd_resample_desc &d = h_desc[i];
-    size_t refl = 0;
-    const size_t of = d.frames > 0 ? bl_rs_out_frames(&geo, (size_t)d.frames, &refl) : 0;
-    if (of == 0 || of > (size_t)INT32_MAX / 2 || (d.channels != 1 && d.channels != 2) ||
-        (d.out_offset & 1) || (d.channels == 2 && (d.in_offset & 1))) {
-      fprintf(stderr,
-              "bliss_amd: resample: song %d rejected (frames=%d channels=%d in_offset=%llu out_offset=%llu): "
-              "need frames > filter length (%d), channels 1|2, even offsets\n",
-              i, d.frames, d.channels, (unsigned long long)d.in_offset, (unsigned long long)d.out_offset,
-              c->rs_taps);
-      return BL_UNEXPECTED;
-    }
-    hs[i].in_off = d.in_offset;
-    hs[i].out_off = d.out_offset;
-    hs[i].frames = d.frames;
-    hs[i].channels = d.channels;
-    hs[i].out_frames = (int)of;
-    hs[i].refl = (int)refl;
-  }
-  if (c->ws_used) BL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ws, 0));
-  if (blr_ensure(c->rs_songs, sizeof(bl_rs_dsong) * (size_t)n_songs) != BL_OK) return BL_UNEXPECTED;
-  bl_rs_dsong *d_songs = static_cast<bl_rs_dsong *>(c->rs_songs.p);
-  BL_HIP_CHECK(hipMemcpyAsync(d_songs, hs, sizeof(bl_rs_dsong) * (size_t)n_songs, hipMemcpyHostToDevice, s));
-  BL_HIP_CHECK(hipEventRecord(slot->ev, s));
-  slot->busy = true;
-  const int G = BL_GROUP_SONGS_MAX;
-  for (int b = 0; b < n_songs; b += G) {
-    const int cnt = std::min(G, n_songs - b);
-    int max_out = 0;
-    for (int i = 0; i < cnt; ++i) max_out = std::max(max_out, hs[b + i].out_frames);
-    if (blk_resample(s, d_in, in_is_s32, d_songs + b, cnt, max_out, c->rs_bank.p, c->rs_geom, c->rs_lds,
-                     c->rs_bank_lds, d_out) != BL_OK)
-      return BL_UNEXPECTED;
-  }
-  BL_HIP_CHECK(hipEventRecord(c->ev_ws, s));
-  c->ws_used = true;
-  return BL_OK;
+  return blr_resample_device(c, d_in, in_is_s32, h_desc, n_songs, in_rate, d_out, static_cast<hipStream_t>(stream));
 }
 
 int bl_amd_resample_batch_device(const void *d_in, int in_is_s32, const bl_amd_resample_desc *h_desc,
@@ -876,6 +947,7 @@ int bl_amd_resample_batch_device(const void *d_in, int in_is_s32, const bl_amd_r
   return bl_amd_ctx_resample_batch_device(blr_default_ctx(), d_in, in_is_s32, h_desc, n_songs, in_rate,
                                           d_out, stream);
 }
+
 
 /* ---- helpers behind the reference-API shims of bl_api.c ---- */
 int bld_analyze_one_host(const int16_t *h_pcm, int n, int channels, uint64_t duration, int what,

@@ -110,6 +110,15 @@ int bl_amd_set_host_transfer(int mode);
 int bl_amd_analyze_batch_host_s32(const int32_t *const *h_pcm, const int32_t *n_samples,
                                   const int32_t *channels, const uint64_t *duration, int n_songs,
                                   bl_amd_song_result *h_results);
+/* Host batches at another sample rate (a 44.1 or 48 kHz collection decoded by the caller):
+ * every song is at `sample_rate` Hz, int16 or (pcm_is_s32) int32 left-justified, n_samples[i]
+ * interleaved samples at that rate.  Each wave of songs is converted on the device between its
+ * transfer and its analysis (bl_amd_resample_batch_device's arithmetic); the results describe
+ * the converted songs (nb_frames etc. at 22 050 Hz stereo).  sample_rate == 22 050 is the plain
+ * host batch.  Blocking. */
+int bl_amd_analyze_batch_host_rate(const void *const *h_pcm, int pcm_is_s32, const int32_t *n_samples,
+                                   const int32_t *channels, const uint64_t *duration, int n_songs,
+                                   int sample_rate, bl_amd_song_result *h_results);
 /* The same narrowing for a device-resident int32 buffer: d_out[i] = (int16)(d_in[i] >> 16). */
 int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void *stream);
 

@@ -101,6 +101,39 @@ def test_converted_batch_feeds_the_analysis(gpu_lib, oracle):
             assert abs(float(r[k][i]) - o[k]) <= 1e-4 * max(1.0, abs(o[k])), (i, k)
 
 
+@pytest.mark.parametrize("rate,kind", [(44100, "s16"), (48000, "s32")])
+def test_host_batch_at_native_rate(gpu_lib, oracle, rate, kind):
+    """bl_amd_analyze_batch_host_rate: host PCM at 44.1 / 48 kHz -> transfer, device conversion,
+    analysis, in waves; against host converter + CPU oracle.  One mono song in the batch."""
+    secs = 9
+    songs, chans = [], [2, 1, 2]
+    for i, ch in enumerate(chans):
+        s = oracle.synth(20 + i, rate, ch, rate * ch * secs + 2 * i * ch).astype(np.int64)
+        if kind == "s32":
+            s = (s << 16) + (np.arange(s.size) * 2654435761 % 65536)
+            songs.append(s.astype(np.int32))
+        else:
+            songs.append(s.astype(np.int16))
+    r = bliss_amd.analyze_batch_host_rate(songs, chans, secs, rate)
+    for i, (s, ch) in enumerate(zip(songs, chans)):
+        pcm = bliss_amd.resample_host(s, ch, rate)
+        o = oracle.analyze(pcm, 2, secs)
+        assert r["status"][i] == 0
+        for k in ("start", "end", "mean", "variance", "n_frames", "nb_frames", "beat"):
+            assert int(r[k][i]) == int(o[k]), (rate, kind, i, k)
+        for k in ("tempo", "amplitude", "frequency", "attack"):
+            assert abs(float(r[k][i]) - o[k]) <= 1e-4 * max(1.0, abs(o[k])), (rate, kind, i, k)
+    # 22 050 Hz through the same entry point is the plain host batch
+    plain = [oracle.synth(30, 22050, 2, 22050 * 2 * 6)]
+    a = bliss_amd.analyze_batch_host_rate(plain, 2, 6, 22050)
+    b = bliss_amd.analyze_batch_host(plain, 2, 6)
+    assert all(np.array_equal(a[k], b[k]) for k in a.dtype.names)
+    # too short to convert / odd sample count for stereo: rejected before anything is staged
+    ptr_bad = [np.zeros(40, np.int16)]
+    with pytest.raises(RuntimeError):
+        bliss_amd.analyze_batch_host_rate(ptr_bad, 2, 1, 44100)
+
+
 def test_converter_rejects_bad_descriptors(gpu_lib):
     import torch
     d_in = torch.zeros(1 << 16, dtype=torch.int16, device="cuda")

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct PCM buffers cycled through the batch")
     ap.add_argument("--mode", choices=("staged", "registered"), default="staged")
     ap.add_argument("--latency", action="store_true", help="also: raw pinned H2D rate, single-song latencies")
+    ap.add_argument("--native-rate", type=int, default=0,
+                    help="treat the buffers as PCM at this rate: bl_amd_analyze_batch_host_rate converts each "
+                         "wave to 22 050 Hz on the device before the analysis")
     a = ap.parse_args()
     import bliss_amd
     lib = bliss_amd.load()
@@ -39,9 +42,13 @@ def main():
         pcm = bufs[: a.songs]
     else:
         pcm = [bufs[i % a.distinct] for i in range(a.songs)]
-    bliss_amd.analyze_batch_host(pcm[: min(160, a.songs)], 2, a.seconds)         # warm-up: both pinned buffers at full size
+    if a.native_rate:
+        run = lambda songs: bliss_amd.analyze_batch_host_rate(songs, 2, a.seconds, a.native_rate)
+    else:
+        run = lambda songs: bliss_amd.analyze_batch_host(songs, 2, a.seconds)
+    run(pcm[: min(160, a.songs)])         # warm-up: both pinned buffers at full size
     t0 = time.perf_counter()
-    res = bliss_amd.analyze_batch_host(pcm, 2, a.seconds)
+    res = run(pcm)
     dt = time.perf_counter() - t0
     ok = bool(np.all(res["status"] == 0))
     same = all(res["tempo"][i] == res["tempo"][i % a.distinct] and res["attack"][i] == res["attack"][i % a.distinct]
@@ -49,6 +56,8 @@ def main():
     line = {"mode": a.mode, "songs": a.songs, "seconds_per_song": a.seconds, "wall_s": round(dt, 3),
             "songs_per_s": round(a.songs / dt, 1), "GB_per_s_pcm": round(a.songs * n * 2 / dt / 1e9, 2),
             "status_ok": ok, "repeats_identical": same}
+    if a.native_rate:
+        line["native_rate"] = a.native_rate
     if a.latency:
         import ctypes as C
         import torch
