@@ -17,6 +17,11 @@
  * STREAMINFO MD5 of the reference's audio/song_s32*.flac (tests/test_ingest.py);
  * the same-rate narrowing step is libswresample's and stays parity-unpinned.
  *
+ * Integrity.  Every FLAC frame's CRC-8 / CRC-16 is checked, frame numbers must follow each
+ * other and the decoded length must equal STREAMINFO's: a damaged or truncated file fails
+ * (BL_UNEXPECTED) instead of being analysed with altered or missing audio.  The stored MD5 of the
+ * whole stream is checked on request (bl_amd_flac_verify), not on every decode.
+ *
  * Sample rate.  The reference always hands 22 050 Hz PCM to the analyzers
  * (ref src/decode.c:7-9,317-346), and every analyzer constant assumes it: a file at any other
  * rate is converted (bl_resample.c, a restatement of libswresample's default resampler pinned
@@ -442,6 +447,35 @@ static void flac_tags(const uint8_t *body, uint32_t sz32, struct bl_song *song) 
 
 /* sig (optional): receives the MD5 of the decoded samples at their native width (what FLAC
  * calls the signature of the unencoded audio) and the signature stored in STREAMINFO */
+/* FLAC frame checksums: CRC-8 (x^8 + x^2 + x + 1) over the frame header, CRC-16 (x^16 + x^15 +
+ * x^2 + 1) over the whole frame.  A header whose CRC-8 does not match is a false sync code
+ * inside audio data and is skipped; a frame whose CRC-16 does not match is damaged audio, and
+ * the decode fails instead of handing altered samples to the analyzers. */
+static uint8_t flac_crc8(const uint8_t *p, size_t n) {
+  uint8_t c = 0;
+  for (size_t i = 0; i < n; ++i) {
+    c ^= p[i];
+    for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : c << 1);
+  }
+  return c;
+}
+
+static uint16_t flac_crc16(const uint8_t *p, size_t n) {
+  static uint16_t tab[256];
+  static int ready = 0;
+  if (!ready) {
+    for (int v = 0; v < 256; ++v) {
+      uint16_t c = (uint16_t)(v << 8);
+      for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1);
+      tab[v] = c;
+    }
+    ready = 1;
+  }
+  uint16_t c = 0;
+  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ tab[(c >> 8) ^ p[i]]);
+  return c;
+}
+
 typedef struct {
   md5_state md;
   uint8_t stored[16];
@@ -491,6 +525,7 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
   static const uint32_t bs_tab[16] = {0,    192,  576,  1152, 2304, 4608, 0,     0,
                                       256,  512,  1024, 2048, 4096, 8192, 16384, 32768};
   int rc = BL_OK;
+  uint64_t frames_seen = 0, frames_done = 0; /* FLAC frames / inter-channel sample frames decoded */
   while (pos + 6 < len) {
     if (d[pos] != 0xFF || (d[pos + 1] & 0xFE) != 0xF8) { ++pos; continue; } /* resync */
     bitrd b;
@@ -498,23 +533,32 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
     uint32_t bs_code = br_bits(&b, 4), sr_code = br_bits(&b, 4);
     uint32_t chan = br_bits(&b, 4), ss_code = br_bits(&b, 3);
     if (br_bits(&b, 1) || sr_code == 15 || bs_code == 0 || chan > 10) { ++pos; continue; }
-    /* UTF-8 style coded frame/sample number */
+    /* UTF-8 style coded frame number (fixed block size) or first-sample number (variable) */
     uint32_t first = br_bits(&b, 8);
     int extra = 0;
     if (first >= 0xFE) extra = 6; else if (first >= 0xFC) extra = 5; else if (first >= 0xF8) extra = 4;
     else if (first >= 0xF0) extra = 3; else if (first >= 0xE0) extra = 2; else if (first >= 0xC0) extra = 1;
     else if (first >= 0x80) { ++pos; continue; }
-    for (int i = 0; i < extra; ++i) br_bits(&b, 8);
+    uint64_t coded = extra ? (first & (0x3Fu >> extra)) : first;
+    for (int i = 0; i < extra; ++i) coded = (coded << 6) | (br_bits(&b, 8) & 0x3F);
+    const int variable_blocks = d[pos + 1] & 1;
     uint32_t blocksize = bs_tab[bs_code];
     if (bs_code == 6) blocksize = br_bits(&b, 8) + 1;
     else if (bs_code == 7) blocksize = br_bits(&b, 16) + 1;
     if (sr_code == 12) br_bits(&b, 8);
     else if (sr_code == 13 || sr_code == 14) br_bits(&b, 16);
-    br_bits(&b, 8); /* CRC-8 (not verified) */
+    {
+      const size_t hdr_end = br_bytepos(&b);
+      const uint32_t crc8 = br_bits(&b, 8);
+      if (b.err || hdr_end > len || flac_crc8(d + pos, hdr_end - pos) != crc8) { ++pos; continue; }
+    }
     if (blocksize == 0 || blocksize > maxb + 16) { ++pos; continue; }
     static const uint32_t ss_tab[8] = {0, 8, 12, 0, 16, 20, 24, 32};
     uint32_t bps = ss_code == 0 ? fi.bps : ss_tab[ss_code];
     if (bps != fi.bps) { rc = BL_UNEXPECTED; break; } /* reserved code or a mid-stream change */
+    /* frames follow each other without gaps: a frame lost to damage (its header no longer
+     * passes the CRC-8 and was skipped as a false sync) shows up here */
+    if (coded != (variable_blocks ? frames_done : frames_seen)) { rc = BL_UNEXPECTED; break; }
     uint32_t nch = chan < 8 ? chan + 1 : 2;
     if (nch != fi.channels) { rc = BL_UNEXPECTED; break; }
     int bad = 0;
@@ -525,8 +569,14 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
     }
     if (bad) { rc = BL_UNEXPECTED; break; }
     br_align(&b);
-    br_bits(&b, 16); /* CRC-16 (not verified) */
+    {
+      const size_t body_end = br_bytepos(&b);
+      const uint32_t crc16 = br_bits(&b, 16);
+      if (b.err || body_end > len || flac_crc16(d + pos, body_end - pos) != crc16) { rc = BL_UNEXPECTED; break; }
+    }
     pos = br_bytepos(&b);
+    ++frames_seen;
+    frames_done += blocksize;
     if (sink_reserve(sink, (size_t)blocksize * nch)) { rc = BL_UNEXPECTED; break; }
     for (uint32_t i = 0; i < blocksize; ++i) {
       int32_t l = ch[0][i], r = nch == 2 ? ch[1][i] : 0;
@@ -553,6 +603,7 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
   free(ch[0]);
   const size_t n = sink->n;
   if (rc != BL_OK || n == 0) return BL_UNEXPECTED;
+  if (fi.total && frames_done != fi.total) return BL_UNEXPECTED; /* truncated, or frames lost at the end */
   song->nSamples = (int)n;
   song->channels = (int)fi.channels;
   song->sample_rate = (int)fi.rate;

@@ -280,6 +280,28 @@ def test_malformed_vorbis_comment_lengths(lib, tmp_path):
     assert rc == _lib.BL_OK and meta["title"] == b"Hey"
 
 
+def test_damaged_flac_frame_is_rejected(lib, tmp_path):
+    """One flipped bit inside a frame's audio data breaks the frame's CRC-16; inside a frame header
+    it breaks the CRC-8, the header is skipped as a false sync and the next frame's number no longer
+    follows; a truncated file ends short of STREAMINFO's sample count.  In every case the decode
+    fails instead of analysing altered or partial audio."""
+    flac = bytearray(open(os.path.join(GOLD, "song.flac"), "rb").read())
+    rc, ref, _ = _decode(lib, os.path.join(GOLD, "song.flac"))
+    assert rc == _lib.BL_OK
+    rng = np.random.default_rng(9)
+    for trial in range(12):
+        data = bytearray(flac)
+        pos = int(rng.integers(20000, len(data) - 1000))   # well inside the audio frames
+        data[pos] ^= 1 << int(rng.integers(0, 8))
+        p = tmp_path / f"d{trial}.flac"
+        p.write_bytes(bytes(data))
+        rc, pcm, _ = _decode(lib, p)
+        assert rc == _lib.BL_UNEXPECTED, (trial, pos)
+    p = tmp_path / "short.flac"
+    p.write_bytes(bytes(flac[: len(flac) * 2 // 3]))
+    assert _decode(lib, p)[0] == _lib.BL_UNEXPECTED
+
+
 def test_decoder_survives_corrupted_files(lib, tmp_path):
     """Byte flips, truncations and garbage tails of a real FLAC and of a WAV: bl_audio_decode may
     fail or succeed, but it returns (no crash, no hang) and leaves a struct that bl_free_song
