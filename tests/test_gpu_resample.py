@@ -53,6 +53,7 @@ def _device_convert(songs, channels, rate):
     (8000, "s16"), (11025, "s32"),        # up-sampling (factor 1, 32 taps)
     (88200, "s16"), (88200, "s32"),       # one phase, step 4, 132 taps
     (192000, "s32"), (176400, "s16"),     # bank too large for the LDS: read through L1/L2
+    (44099, "s16"), (22051, "s32"), (12345, "s16"),   # no small rational: 1 024 phases, fractional stepping
 ])
 def test_device_equals_host_bit_for_bit(gpu_lib, rate, kind):
     rng = np.random.default_rng(rate + (kind == "s32"))
