@@ -118,7 +118,7 @@ struct bl_rs_dsong {
 };
 
 struct bl_rs_geom {
-  int phase_count, taps, taps8, alloc, w0, span;
+  int phase_count, taps, taps8, alloc, w0, span, tiles_per_wg;
   unsigned long long src_incr, dst_incr;
 };
 

@@ -17,10 +17,11 @@
  *                  wave takes one phase at a time (taps wave-uniform), its lanes outputs one
  *                  cycle apart, the next tile's input is fetched while one is computed;
  *   k_resample     everything else (other rates, up-sampling): one workgroup converts RS_TILE
- *                  consecutive output frames; it stages the input span those outputs read and,
- *                  when it fits, the bank into LDS (rows padded to an odd stride so that lanes
- *                  on different phases spread over the banks), one output frame per lane at a
- *                  time — LDS-read bound, taps * (1 coefficient + channels samples) reads per frame.
+ *                  consecutive output frames; it stages the input span those outputs read as
+ *                  (L, R) pairs and, when it fits, the bank into LDS (rows 16-byte aligned, an
+ *                  odd number of 16-byte units apart, so that lanes on different phases spread
+ *                  over the banks), one output frame per lane at a time — LDS-read bound: taps *
+ *                  12 bytes per output frame.
  * All three reflect the input at the song's edges exactly as the host form does.
  */
 #include <hip/hip_runtime.h>
@@ -35,6 +36,7 @@
 
 #define RS_TILE 1024
 #define RS_THREADS 256
+#define RSG_THREADS 1024 /* generic kernel: its LDS footprint allows one workgroup per CU */
 #define RS_LDS_LIMIT (160 * 1024)
 
 namespace {
@@ -44,56 +46,58 @@ template <> struct rs_elem<true> { typedef float type; };
 
 __device__ __forceinline__ int rs_clip16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
 
-template <bool F32, bool STEREO>
-__device__ __forceinline__ unsigned rs_output(const typename rs_elem<F32>::type *__restrict__ x0,
-                                              const typename rs_elem<F32>::type *__restrict__ x1,
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+typedef int rs_i2 __attribute__((ext_vector_type(2)));
+template <bool F32> struct rs_pair { typedef rs_i2 type; };
+template <> struct rs_pair<true> { typedef rs_f2 type; };
+
+/* one output frame: x = the window's frames as (L, R) pairs, c = its row of taps (16-byte aligned,
+ * zero padded to taps8) */
+template <bool F32>
+__device__ __forceinline__ unsigned rs_output(const typename rs_pair<F32>::type *__restrict__ x,
                                               const typename rs_elem<F32>::type *__restrict__ c, int taps8) {
   if constexpr (F32) {
-    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < taps8; i += 8) {
+    rs_f2 a[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float cf = c[i + q];
-        a[q] = __builtin_fmaf(x0[i + q], cf, a[q]);
-        if (STEREO) b[q] = __builtin_fmaf(x1[i + q], cf, b[q]);
-      }
+    for (int q = 0; q < 8; ++q) a[q] = rs_f2{0.0f, 0.0f};
+    for (int i = 0; i < taps8; i += 8) {
+      const float4 c0 = *reinterpret_cast<const float4 *>(c + i), c1 = *reinterpret_cast<const float4 *>(c + i + 4);
+      const float cf[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] = __builtin_elementwise_fma(x[i + q], rs_f2{cf[q], cf[q]}, a[q]);
     }
-    const float va = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
-    float ra = rintf(va * 32768.0f);
-    ra = fminf(fmaxf(ra, -32768.0f), 32767.0f);
-    const unsigned l = (unsigned)(int)ra & 0xFFFFu;
-    if (!STEREO) return l | (l << 16);
-    const float vb = ((b[0] + b[4]) + (b[2] + b[6])) + ((b[1] + b[5]) + (b[3] + b[7]));
-    float rb = rintf(vb * 32768.0f);
-    rb = fminf(fmaxf(rb, -32768.0f), 32767.0f);
-    return l | ((unsigned)(int)rb << 16);
+    const rs_f2 v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+    const float ra = fminf(fmaxf(rintf(v.x * 32768.0f), -32768.0f), 32767.0f);
+    const float rb = fminf(fmaxf(rintf(v.y * 32768.0f), -32768.0f), 32767.0f);
+    return ((unsigned)(int)ra & 0xFFFFu) | ((unsigned)(int)rb << 16);
   } else {
-    unsigned a = 1u << 14, b = 1u << 14;
+    int a = 1 << 14, b = 1 << 14; /* wraps like the host's accumulator */
     for (int i = 0; i < taps8; i += 8) {
+      const int4 c0 = *reinterpret_cast<const int4 *>(c + i), c1 = *reinterpret_cast<const int4 *>(c + i + 4);
+      const int cf[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int cf = c[i + q];
-        a += (unsigned)(x0[i + q] * cf);
-        if (STEREO) b += (unsigned)(x1[i + q] * cf);
+      for (int q = 0; q < 8; ++q) { /* 16-bit operands: the 24-bit multiplier is exact */
+        const rs_i2 v = x[i + q];
+        a = (int)((unsigned)a + (unsigned)__mul24(v.x, cf[q]));
+        b = (int)((unsigned)b + (unsigned)__mul24(v.y, cf[q]));
       }
     }
-    const unsigned l = (unsigned)rs_clip16((int)a >> 15) & 0xFFFFu;
-    if (!STEREO) return l | (l << 16);
-    return l | ((unsigned)rs_clip16((int)b >> 15) << 16);
+    return ((unsigned)rs_clip16(a >> 15) & 0xFFFFu) | ((unsigned)rs_clip16(b >> 15) << 16);
   }
 }
 
 template <bool F32, bool BANK_LDS>
-__global__ __launch_bounds__(RS_THREADS) void k_resample(const void *__restrict__ in,
+__global__ __launch_bounds__(RSG_THREADS) void k_resample(const void *__restrict__ in,
                                                          const bl_rs_dsong *__restrict__ songs,
                                                          const void *__restrict__ bank_g, bl_rs_geom G,
                                                          int16_t *__restrict__ out) {
   typedef typename rs_elem<F32>::type T;
+  typedef typename rs_pair<F32>::type T2;
   extern __shared__ __align__(16) unsigned char rs_smem[];
   const bl_rs_dsong sg = songs[blockIdx.y];
-  const long long n0 = (long long)blockIdx.x * RS_TILE;
-  if (n0 >= sg.out_frames) return;
-  const int cnt = (int)min((long long)RS_TILE, (long long)sg.out_frames - n0);
+  const long long n_begin = (long long)blockIdx.x * G.tiles_per_wg * RS_TILE;
+  if (n_begin >= sg.out_frames) return;
+  const long long n_end = min((long long)sg.out_frames, n_begin + (long long)G.tiles_per_wg * RS_TILE);
   const int tid = threadIdx.x;
   const unsigned pc = (unsigned)G.phase_count;
   const int L = G.taps, taps8 = G.taps8;
@@ -104,73 +108,77 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample(const void *__restrict_
     index = (int)(t % pc);
     return (long long)G.w0 + (long long)(t / pc);
   };
-  int idx_unused;
-  const long long w_first = position(n0, idx_unused);
-  const long long w_last = position(n0 + cnt - 1, idx_unused);
-  const int span = (int)(w_last - w_first) + taps8;
 
-  T *x0 = reinterpret_cast<T *>(rs_smem);
-  T *x1 = x0 + G.span;
-  T *lb = x1 + G.span;
-  const int lb_stride = taps8 + 1;
-
-  /* input span: ext position e = w_first + k; ext[0..L) mirrors the first samples about
-   * sample 0, ext[L + N ...] mirrors the last `refl` about the end, nothing beyond */
-  const long long N = sg.frames;
-  for (int k = tid; k < span; k += RS_THREADS) {
-    const long long e = w_first + k - L;
-    long long xi = e;
-    bool ok = true;
-    if (e < 0) xi = -e;
-    else if (e >= N) {
-      const long long j = e - N;
-      ok = j < sg.refl;
-      xi = N - 1 - j;
-    }
-    T a = 0, b = 0;
-    if (ok) {
-      if constexpr (F32) {
-        const int32_t *p = static_cast<const int32_t *>(in) + sg.in_off;
-        if (stereo) {
-          const int2 v = reinterpret_cast<const int2 *>(p)[xi];
-          a = (float)v.x * (1.0f / 2147483648.0f);
-          b = (float)v.y * (1.0f / 2147483648.0f);
-        } else {
-          a = (float)p[xi] * (1.0f / 2147483648.0f) * (float)0.70710678118654752440;
-        }
-      } else {
-        const int16_t *p = static_cast<const int16_t *>(in) + sg.in_off;
-        if (stereo) {
-          const unsigned v = reinterpret_cast<const unsigned *>(p)[xi];
-          a = (int)(short)(v & 0xFFFFu);
-          b = (int)(short)(v >> 16);
-        } else {
-          a = ((int)p[xi] * 23170 + 16384) >> 15; /* Q15 1/sqrt(2) */
-        }
-      }
-    }
-    x0[k] = a;
-    if (stereo) x1[k] = b;
-  }
-  if (BANK_LDS) {
+  T2 *xs = reinterpret_cast<T2 *>(rs_smem);   /* frames as (L, R); a mono source in both */
+  T *lb = reinterpret_cast<T *>(xs + G.span); /* G.span is even: 16-byte aligned */
+  const int lb_stride = taps8 + 4;            /* rows 16-byte aligned, an odd number of 16-byte units apart */
+  if (BANK_LDS) { /* once per workgroup: it walks a run of tiles */
     const T *bg = static_cast<const T *>(bank_g);
     const int total = (int)pc * taps8;
-    for (int i = tid; i < total; i += RS_THREADS) {
+    for (int i = tid; i < total; i += RSG_THREADS) {
       const int r = i / taps8, q = i - r * taps8;
       lb[r * lb_stride + q] = bg[(size_t)r * G.alloc + q];
     }
   }
+
+  for (long long n0 = n_begin; n0 < n_end; n0 += RS_TILE) {
+  const int cnt = (int)min((long long)RS_TILE, n_end - n0);
+  int idx_unused;
+  const long long w_first = position(n0, idx_unused);
+  const long long w_last = position(n0 + cnt - 1, idx_unused);
+  const int span = (int)(w_last - w_first) + taps8;
+  __syncthreads(); /* the previous tile's windows have been read */
+
+  /* input span: ext position e = w_first + k; ext[0..L) mirrors the first samples about
+   * sample 0, ext[L + N ...] mirrors the last `refl` about the end, nothing beyond */
+  const long long N = sg.frames;
+  for (int k0 = tid; k0 < span; k0 += 4 * RSG_THREADS) {
+    T2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { /* four loads in flight; clamped, not masked (a masked load is waited for at once) */
+      const long long e = w_first + (k0 + u * RSG_THREADS) - L;
+      const long long j = e - N;
+      long long xi = e < 0 ? -e : (e < N ? e : N - 1 - j);
+      const bool ok = j < sg.refl;
+      xi = min(max(xi, 0LL), N - 1);
+      if constexpr (F32) {
+        const int32_t *p = static_cast<const int32_t *>(in) + sg.in_off;
+        if (stereo) {
+          const int2 q = reinterpret_cast<const int2 *>(p)[xi];
+          v[u].x = (float)q.x * (1.0f / 2147483648.0f);
+          v[u].y = (float)q.y * (1.0f / 2147483648.0f);
+        } else {
+          v[u].x = (float)p[xi] * (1.0f / 2147483648.0f) * (float)0.70710678118654752440;
+          v[u].y = v[u].x;
+        }
+      } else {
+        const int16_t *p = static_cast<const int16_t *>(in) + sg.in_off;
+        if (stereo) {
+          const unsigned q = reinterpret_cast<const unsigned *>(p)[xi];
+          v[u].x = (int)(short)(q & 0xFFFFu);
+          v[u].y = (int)(short)(q >> 16);
+        } else {
+          v[u].x = ((int)p[xi] * 23170 + 16384) >> 15; /* Q15 1/sqrt(2) */
+          v[u].y = v[u].x;
+        }
+      }
+      if (!ok) v[u] = T2{0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u * RSG_THREADS < span) xs[k0 + u * RSG_THREADS] = v[u];
+  }
   __syncthreads();
 
   unsigned *o = reinterpret_cast<unsigned *>(out + sg.out_off) + n0;
-  for (int j = tid; j < cnt; j += RS_THREADS) {
+  for (int j = tid; j < cnt; j += RSG_THREADS) {
     int index;
     const long long w = position(n0 + j, index);
     const int base = (int)(w - w_first);
     const T *c = BANK_LDS ? lb + index * lb_stride : static_cast<const T *>(bank_g) + (size_t)index * G.alloc;
-    o[j] = stereo ? rs_output<F32, true>(x0 + base, x1 + base, c, taps8)
-                  : rs_output<F32, false>(x0 + base, x0 + base, c, taps8);
+    o[j] = rs_output<F32>(xs + base, c, taps8);
   }
+  } /* tiles */
 }
 
 /* ---- one phase, whole-number step: 44.1 kHz (step 2, 66 taps) and 88.2 kHz (step 4, 132) ----
@@ -187,7 +195,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample(const void *__restrict_
  * off its neighbours' banks.  A mono source is staged into both channels. */
 #define RS1_OUT 4
 typedef short rs_s2 __attribute__((ext_vector_type(2)));
-typedef float rs_f2 __attribute__((ext_vector_type(2)));
 
 template <bool F32, int D, int L> struct rs1_geom {
   static constexpr int F = L + (RS1_OUT - 1) * D;                    /* frames one lane reads */
@@ -718,9 +725,14 @@ int rs_launch(hipStream_t s, const void *d_in, const bl_rs_dsong *d_songs, int n
                                      hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_LIMIT));
     configured[dev] = true;
   }
-  const unsigned tiles = (unsigned)((max_out_frames + RS_TILE - 1) / RS_TILE);
-  hipLaunchKernelGGL((k_resample<F32, BANK_LDS>), dim3(tiles, (unsigned)n_songs), dim3(RS_THREADS), lds, s,
-                     d_in, d_songs, d_bank, g, d_out);
+  /* a workgroup walks a run of tiles so that the bank is staged once for all of them; short
+   * runs when the batch is small */
+  const long long tiles = (max_out_frames + RS_TILE - 1) / RS_TILE;
+  bl_rs_geom gg = g;
+  gg.tiles_per_wg = (int)std::min<long long>(16, std::max<long long>(1, tiles * n_songs / 2048));
+  const unsigned groups = (unsigned)((tiles + gg.tiles_per_wg - 1) / gg.tiles_per_wg);
+  hipLaunchKernelGGL((k_resample<F32, BANK_LDS>), dim3(groups, (unsigned)n_songs), dim3(RSG_THREADS), lds, s,
+                     d_in, d_songs, d_bank, gg, d_out);
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }
@@ -739,9 +751,9 @@ int blk_resample_geom(int phase_count, int taps, int alloc, int src_incr, int ds
   /* the widest input span a tile can read: first to last window start, plus one window */
   const unsigned long long adv =
       (unsigned long long)(RS_TILE - 1) * g->dst_incr / (g->src_incr * (unsigned long long)phase_count);
-  g->span = (int)adv + 2 + g->taps8;
-  const size_t samples = 2 * (size_t)g->span * 4;
-  const size_t bank = (size_t)phase_count * (size_t)(g->taps8 + 1) * 4;
+  g->span = ((int)adv + 2 + g->taps8 + 1) & ~1;
+  const size_t samples = (size_t)g->span * 8; /* (L, R) pairs of 32-bit elements */
+  const size_t bank = (size_t)phase_count * (size_t)(g->taps8 + 4) * 4;
   if (samples > RS_LDS_LIMIT) return BL_UNEXPECTED;
   *bank_in_lds = samples + bank <= RS_LDS_LIMIT;
   *lds_bytes = samples + (*bank_in_lds ? bank : 0);
