@@ -950,6 +950,283 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 }
 
 /* ------------------------------------------------------------------------- */
+/* k_env_windows3: the same arithmetic, every FIR output computed once          */
+/*
+ * k_env_windows2 filters 1 280 samples per round of four windows and keeps 1 024: the next
+ * round of the wave is 28 windows away, so the 256 samples its first window shares with the
+ * last one are filtered again (a quarter of the FIR, which is 43 % of the round).  Here a
+ * compute wave walks a CONTIGUOUS run of windows (the song's rounds are split evenly over the
+ * workgroups' compute waves).  The wave's slice holds five blocks of 256 filtered samples as a
+ * ring: a round filters the 1 024 new samples (16 outputs per lane) into the four positions the
+ * previous round has released and finds the block it shares with the previous round where that
+ * round left it — nothing is copied.  The transposes and partner rows of window g use the place
+ * of block g, which every window has finished reading by then; the carried block is nobody's
+ * block g.  Each lane normalises the 32 samples its 16 outputs read from its own loads: no
+ * cross-lane shift, hence no lane 0 that would need the previous round's lane 63.  The first
+ * round of a run is preceded by a short pass that filters the one block it cannot inherit.
+ * Rounds, hand-over to the summing wave, DFT and power terms are those of k_env_windows2;
+ * the energies are bit-identical.
+ */
+#define EV3_BLK 288                          /* doubles per block: 16 rows of 16 samples + 2 pads */
+#define EV3_HEADS (5 * EV3_BLK)
+#define EV3_SLOTS (EV3_HEADS + 64)           /* + 4 x 16 window heads */
+#define EV3_TERMS_OFF (EV2_CWAVES * EV3_SLOTS * 8)
+#define EV3_TW_OFF (EV3_TERMS_OFF + EV2_TILE * EV2_TROW * 8)
+#define EV3_FLAG_OFF (EV3_TW_OFF + 2 * 256 * 16)
+#define EV3_LDS_BYTES (EV3_FLAG_OFF + 64)
+
+__global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
+    const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
+    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *terms = reinterpret_cast<double *>(smem + EV3_TERMS_OFF); /* [EV2_TILE][257] */
+  c2d *tw256 = reinterpret_cast<c2d *>(smem + EV3_TW_OFF);
+  c2d *tw512 = tw256 + 256;
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  lds_vint *flags = (lds_vint *)(smem + EV3_FLAG_OFF); /* as in k_env_windows2 */
+
+  const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63, g = ln >> 4, l = ln & 15;
+  const bl_dsong sg = songs[blockIdx.y];
+  const bl_dstats st = stats[blockIdx.y];
+  const int16_t *p = pcm + sg.pcm_off;
+  if (tid < 256) {
+    tw256[tid] = tb.tw256_d[((tid & 15) * (tid >> 4)) & 255];
+    tw512[tid] = tb.tw512_d[tid];
+  }
+  if (tid < 16) flags[tid] = 0;
+  __syncthreads();
+
+  /* rounds of four windows, split evenly over the compute waves of the song's workgroups */
+  const int n_rounds = (sg.n_windows + 3) / 4;
+  const int n_units = EV2_CWAVES * (int)gridDim.x;
+  auto run_begin = [&](int u) -> int { return (int)((long long)n_rounds * u / n_units); };
+  const int u0 = EV2_CWAVES * (int)blockIdx.x;
+  int steps = 0;
+  for (int c = 0; c < EV2_CWAVES; ++c) steps = max(steps, run_begin(u0 + c + 1) - run_begin(u0 + c));
+  const int n_used = 256 * (sg.n_windows + 1);
+  int seq = 0;
+
+  if (wave == EV2_CWAVES) {
+    /* ---- summing wave: lane 4 c + q sums window q of compute wave c's current round ---- */
+    __builtin_amdgcn_s_setprio(3);
+    const int c = min(ln >> 2, EV2_CWAVES - 1);
+    const int r0 = run_begin(u0 + c), r1 = run_begin(u0 + c + 1);
+    for (int s = 0; s < steps; ++s) {
+      ++seq;
+      for (;;) {
+        const int f = ln < EV2_CWAVES ? flags[ln] : seq;
+        if (__all(f >= seq)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      ev2_lds_acquire();
+      const int rho = r0 + s, w = 4 * rho + (ln & 3);
+      if (ln < EV2_TILE && rho < r1 && w < sg.n_windows) {
+        const double *tg = terms + ln * EV2_TROW;
+        float sum = 0.f;
+        double ta[32], tb2[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) ta[k] = tg[k];
+#pragma unroll 1
+        for (int blk = 0; blk < 8; blk += 2) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) tb2[k] = tg[32 * (blk + 1) + k];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + ta[k]);
+          if (blk + 2 < 8) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) ta[k] = tg[32 * (blk + 2) + k];
+          }
+#pragma unroll
+          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + tb2[k]);
+        }
+        sum = (float)((double)sum + tg[256]);
+        energies[sg.env_off + w] = sum;
+        lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
+      }
+      ev2_lds_release();
+      if (ln == 0) flags[8] = seq;
+    }
+    return;
+  }
+
+  /* ---- compute waves ---- */
+  double *buf = reinterpret_cast<double *>(smem) + wave * EV3_SLOTS;
+  const int mean = st.mean;
+  const double rcp = st.rcp, rcp_lo = st.rcp_lo;
+  const int r0 = run_begin(u0 + wave), r1 = run_begin(u0 + wave + 1);
+  c2d w1r[16];
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) {
+    w1r[k1] = tw256[k1 * 16 + l];
+    asm volatile("" : "+v"(w1r[k1].re), "+v"(w1r[k1].im));
+  }
+  int base5 = (4 * r0) % 5; /* ring position of block 4 rho, the block shared with the previous round */
+
+  if (r0 < r1) { /* the block the first round cannot inherit: samples [1024 r0, 1024 r0 + 256) */
+    const int s0 = 1024 * r0 + 4 * ln; /* this lane's 4 outputs; inputs [s0 - 16, s0 + 4) */
+    double r[20];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i0 = s0 - 16 + 4 * u;
+      const bool ok = i0 >= 0 && i0 + 4 <= n_used;
+      const uint2 v = *reinterpret_cast<const uint2 *>(p + (ok ? i0 : 0));
+      const unsigned w[2] = {ok ? v.x : 0u, ok ? v.y : 0u};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
+        r[4 * u + 2 * k] = ok ? bl_norm(lo - mean, rcp, rcp_lo) : 0.0;
+        r[4 * u + 2 * k + 1] = ok ? bl_norm(hi - mean, rcp, rcp_lo) : 0.0;
+      }
+    }
+    double *dst = buf + base5 * EV3_BLK + (ln >> 2) * 18 + 4 * (ln & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#define XW(m) r[i + 16 - (m)]
+      dst[i] = BL_FIR(XW);
+#undef XW
+    }
+  }
+
+  /* lane ln owns outputs 16 ln .. 16 ln + 15 of the round's 1 024 new samples and loads the 32
+   * samples they read (four 16-byte loads), plus the sample that starts its zero-state output;
+   * fetched one round ahead, unconditionally (clamped addresses, values zeroed by a select) */
+  uint4 pre[4];
+  short preh;
+  auto fetch = [&](int rho_) {
+    const bool live = rho_ < r1;
+    const int base = 1024 * rho_ + 240 + 16 * ln; /* first input = first output - 16 */
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i0 = base + 8 * u;
+      const bool ok = live && i0 + 8 <= n_used;
+      const uint4 v = *reinterpret_cast<const uint4 *>(p + (ok ? i0 : 0));
+      pre[u] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+    const int ih = 1024 * rho_ + 256 * g + l;
+    const bool okh = live && ih < n_used;
+    const short vh = p[okh ? ih : 0];
+    preh = okh ? vh : (short)0;
+  };
+  fetch(r0);
+  for (int s = 0; s < steps; ++s) {
+    ++seq;
+    const int rho = r0 + s;
+    if (rho >= r1) { /* this wave's run is one round shorter than its neighbours': nothing to hand over */
+      if (ln == 0) flags[wave] = seq;
+      continue;
+    }
+    /* 1. normalise (ref :109-114) the 32 samples into registers */
+    double yv[16], yh;
+    {
+      double r[32];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned w[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
+          r[8 * u + 2 * k] = bl_norm(lo - mean, rcp, rcp_lo);
+          r[8 * u + 2 * k + 1] = bl_norm(hi - mean, rcp, rcp_lo);
+        }
+      }
+      const double xh = bl_norm((int)preh - mean, rcp, rcp_lo);
+      fetch(rho + 1); /* next round's samples */
+      /* 2. FIR (ref :123-138): outputs 16 ln .. 16 ln + 15 of the round's new samples */
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+#define XR(m) r[i + 16 - (m)]
+        yv[i] = BL_FIR(XR);
+#undef XR
+      }
+      /* zero-state heads of the four windows, as in k_env_windows2 */
+      double hx[17];
+      hx[0] = xh;
+      hx[1] = bl_dpp_f64<0x111>(xh);  hx[2] = bl_dpp_f64<0x112>(xh);  hx[3] = bl_dpp_f64<0x113>(xh);
+      hx[4] = bl_dpp_f64<0x114>(xh);  hx[5] = bl_dpp_f64<0x115>(xh);  hx[6] = bl_dpp_f64<0x116>(xh);
+      hx[7] = bl_dpp_f64<0x117>(xh);  hx[8] = bl_dpp_f64<0x118>(xh);  hx[9] = bl_dpp_f64<0x119>(xh);
+      hx[10] = bl_dpp_f64<0x11A>(xh); hx[11] = bl_dpp_f64<0x11B>(xh); hx[12] = bl_dpp_f64<0x11C>(xh);
+      hx[13] = bl_dpp_f64<0x11D>(xh); hx[14] = bl_dpp_f64<0x11E>(xh); hx[15] = bl_dpp_f64<0x11F>(xh);
+      hx[16] = 0.0;
+#define XH(m) hx[m]
+      yh = BL_FIR(XH);
+#undef XH
+    }
+    /* ring positions: window g reads block g (first half) and block g + 1 (second half); the
+     * lanes of group g have just filtered block g + 1 */
+    const int xa = base5 + g, xb = xa + 1;
+    const int pa = xa >= 5 ? xa - 5 : xa, pb = xb >= 5 ? xb - 5 : xb;
+    double *blk_a = buf + pa * EV3_BLK, *blk_b = buf + pb * EV3_BLK;
+    ev2_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blk_b[18 * l + i] = yv[i];
+    buf[EV3_HEADS + ln] = yh;
+    ev2_wave_sync();
+    /* 3. DFT input of window g: lane l holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
+    double re[16], im[16];
+    {
+      const int off = l < 8 ? 2 * l : 2 * l + 2; /* row 2 m1' or 2 m1' + 1 of the block, 18 doubles each */
+      const double *ia = blk_a + off, *ib = blk_b + off;
+      const double *i0 = l < 8 ? buf + EV3_HEADS + 16 * g + 2 * l : ia;
+      re[0] = i0[0];
+      im[0] = i0[1];
+#pragma unroll
+      for (int m1 = 1; m1 < 8; ++m1) { re[m1] = ia[36 * m1]; im[m1] = ia[36 * m1 + 1]; }
+#pragma unroll
+      for (int m1 = 8; m1 < 16; ++m1) { re[m1] = ib[36 * (m1 - 8)]; im[m1] = ib[36 * (m1 - 8) + 1]; }
+    }
+    ev2_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
+    bl_fft16(re, im);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1)
+      bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w1r[k1].re, w1r[k1].im);
+    double *xg = blk_a; /* [16][18] doubles, re then im */
+    const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = re[bl_pos16(k1)];
+    ev2_wave_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; re[2 * q] = v.x; re[2 * q + 1] = v.y; }
+    ev2_wave_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = im[bl_pos16(k1)];
+    ev2_wave_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
+    ev2_wave_sync();
+    bl_fft16(re, im);
+    double2 *pg = reinterpret_cast<double2 *>(blk_a); /* partner half rows, 9 pairs per lane row */
+#pragma unroll
+    for (int k0 = 8; k0 < 16; ++k0)
+      pg[l * 9 + (k0 - 8)] = make_double2(re[bl_pos16(k0)], im[bl_pos16(k0)]);
+    ev2_wave_sync();
+    double own[8], mir[8];
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+      const int sl = bl_partner_slot(l, k0);
+      double pr = re[bl_pos16(0)], pi = im[bl_pos16(0)];
+      if (sl >= 0) { const double2 v = pg[(sl >> 3) * 9 + (sl & 7)]; pr = v.x; pi = v.y; }
+      bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
+                                      own[k0], mir[k0]);
+    }
+    const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
+    const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
+    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
+    ev2_lds_acquire();
+    double *tg = terms + (4 * wave + g) * EV2_TROW;
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+      tg[l + 16 * k0] = own[k0];
+      tg[256 - l - 16 * k0] = mir[k0];
+    }
+    if (l == 0) tg[128] = mid;
+    ev2_lds_release();
+    ev2_wave_sync();
+    if (ln == 0) flags[wave] = seq;
+    base5 = base5 == 0 ? 4 : base5 - 1; /* (4 (rho + 1)) mod 5 */
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* k_env_tail: one lane per song, three waves per 64 songs                    */
 /*
  * Parts 2-3 of bl_envelope_sort are serial per song.  The 6th-order recurrence is a chain
@@ -1321,6 +1598,8 @@ int blk_configure_device(void) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   return BL_OK;
@@ -1383,10 +1662,14 @@ int blk_analyze(const blk_analyze_args &a) {
       Mark m(a.mark, a.mark_user, PK_ENV, stream);
       /* one 512-thread workgroup per CU; blocks of a song split its 28-window tiles */
       const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2, a.n_cu);
+      static const bool old_env = getenv("BL_AMD_ENV_OLD") != nullptr; /* A/B aid: the round-robin kernel */
       if (a.env_dbg)
         hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
                            EV2_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc,
                            a.env_dbg);
+      else if (!old_env)
+        hipLaunchKernelGGL(k_env_windows3, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
       else
         hipLaunchKernelGGL(k_env_windows2<false>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
                            EV2_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc, 0);
