@@ -309,12 +309,12 @@ def main():
             try:
                 import glob
                 tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
-                tk = tj["kernels"]["k_env_windows2"]
+                tk = tj["kernels"].get("k_env_windows3") or tj["kernels"]["k_env_windows2"]
                 traffic = tk["hbm_bytes_per_song"] * songs * (song_samples / 15876000.0)
                 valu_busy, lds_busy = tk.get("valu_busy_frac"), tk.get("lds_busy_frac")
             except Exception:
                 pass
-            roof = {"bound": "hbm", "kernel": "k_env_windows2", "achieved": ach, "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": "k_env_windows3", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
                                       "profiles/*_hbm_traffic.json, scaled per song",

@@ -16,8 +16,10 @@
  *   k_freq_frames  Hann + 512-pt f32 real DFT power, summed over the frames in the
  *                  reference's order            ref src/frequency_sort.c:67-94
  *   k_freq_finish  dB spectrum, 5 bands, score  ref src/frequency_sort.c:97-139
- *   k_env_windows2 normalise, 17-tap FIR, 512-pt f64 real DFT, f32-rounded
+ *   k_env_windows3 normalise, 17-tap FIR, 512-pt f64 real DFT, f32-rounded
  *                  energy per window            ref src/tempo_atk_sort.c:109-153
+ *                  (k_env_windows2: the round-robin predecessor, kept as the
+ *                  probe instantiation and for BL_AMD_ENV_OLD=1 comparisons)
  *   k_env_tail     IIR, box filters, peaks, tempo/attack
  *                                               ref src/tempo_atk_sort.c:184-284
  *   k_force        force, calm_or_loud          ref src/analyze.c:63-80
