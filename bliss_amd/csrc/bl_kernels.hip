@@ -28,6 +28,7 @@
  *   k_synth        integer synthetic PCM (benchmark corpus)
  */
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1662,8 +1663,10 @@ int blk_analyze(const blk_analyze_args &a) {
   if (what & 4) {
     {
       Mark m(a.mark, a.mark_user, PK_ENV, stream);
-      /* one 512-thread workgroup per CU; blocks of a song split its 28-window tiles */
-      const int gx2 = grid_x_for((2 * max_frames + EV2_TILE - 1) / EV2_TILE, n_songs, 2, a.n_cu);
+      /* one 512-thread workgroup per CU; the blocks of a song split its rounds of four windows
+       * into contiguous runs, one per compute wave: at least four rounds per run, so that the
+       * block a run filters before its first round stays a small part of it */
+      const int gx2 = grid_x_for(std::max(1, (2 * max_frames) / (4 * 4 * EV2_CWAVES)), n_songs, 2, a.n_cu);
       static const bool old_env = getenv("BL_AMD_ENV_OLD") != nullptr; /* A/B aid: the round-robin kernel */
       if (a.env_dbg)
         hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
