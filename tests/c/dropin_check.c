@@ -5,7 +5,9 @@
  * (ref tests/test_analyze.c:30-55, tests/test_decode.c:16-17), at the reference's own 1e-5.
  * Exercises the by-value struct ABI of bl_distance / bl_cosine_similarity, the caller-owned
  * uninitialised struct bl_song, the analyzers on a decoded song and the release path.
- * usage: dropin_check <path to song.flac>; exit status 0 = all checks passed.
+ * With a second argument, the reference's other fixture (audio/song_s32.flac: 48 kHz, 24 bit) is
+ * analysed as ref tests/test_analyze.c:59-89 does: it goes through the rate converter.
+ * usage: dropin_check <path to song.flac> [<path to song_s32.flac>]; exit status 0 = all passed.
  */
 #include <math.h>
 #include <stdio.h>
@@ -102,6 +104,24 @@ int main(int argc, char **argv) {
   bl_free_song(&s1);
   bl_free_song(&s2);
   same_int("bl_analyze(missing)", bl_analyze("/nonexistent/file.flac", &s1), BL_UNEXPECTED);
+
+  if (argc > 2) { /* ref tests/test_analyze.c:59-89 */
+    struct bl_song w;
+    same_int("s32: bl_analyze return", bl_analyze(argv[2], &w), BL_CALM);
+    near("s32: force", w.force, -20.821571, 1e-5);
+    near("s32: tempo", w.force_vector.tempo, -8.218182, 1e-5);
+    near("s32: amplitude", w.force_vector.amplitude, -10.641695, 1e-5);
+    near("s32: frequency", w.force_vector.frequency, -10.179875, 1e-5);
+    near("s32: attack", w.force_vector.attack, -15.561186, 1e-5);
+    same_int("s32: channels", w.channels, 2);
+    same_int("s32: nSamples", w.nSamples, 488140);
+    same_int("s32: sample_rate", w.sample_rate, 22050);
+    same_int("s32: nb_bytes_per_sample", w.nb_bytes_per_sample, 2);
+    same_int("s32: duration", (long)w.duration, 11);
+    same_str("s32: artist", w.artist, "David TMX");
+    same_str("s32: genre", w.genre, "Pop");
+    bl_free_song(&w);
+  }
 
   if (bl_version() <= 0) { puts("FAIL bl_version"); ++failures; }
   bl_free_song(&song);

@@ -394,7 +394,8 @@ def test_invalid_inputs_are_rejected(gpu_lib, tmp_path):
 
 def test_c_caller_links_and_passes(gpu_lib, tmp_path):
     """tests/c/dropin_check.c: a C99 caller compiled against include/bliss.h only and linked against
-    libbliss_amd.so, checking the reference's goldens for song.flac and the by-value struct ABI."""
+    libbliss_amd.so, checking the reference's goldens for song.flac and song_s32.flac (ref
+    tests/test_analyze.c:26-89) and the by-value struct ABI."""
     import subprocess
     root = os.path.dirname(HERE)
     exe = str(tmp_path / "dropin_check")
@@ -402,7 +403,8 @@ def test_c_caller_links_and_passes(gpu_lib, tmp_path):
                     os.path.join(HERE, "c", "dropin_check.c"), "-o", exe,
                     "-L", os.path.join(root, "bliss_amd"), "-lbliss_amd", "-lm",
                     "-Wl,-rpath," + os.path.join(root, "bliss_amd")], check=True)
-    r = subprocess.run([exe, os.path.join(HERE, "golden", "song.flac")], stdout=subprocess.PIPE, text=True)
+    r = subprocess.run([exe, os.path.join(HERE, "golden", "song.flac"), os.path.join(HERE, "golden", "song_s32.flac")],
+                       stdout=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stdout
 
 
