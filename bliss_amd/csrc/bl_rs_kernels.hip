@@ -253,6 +253,18 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
           *reinterpret_cast<float4 *>(xs + k + (k >> 3) * 2) = w;
         }
       }
+    } else if (interior) { /* 8-byte aligned only (an odd first frame): one frame per load, all in flight */
+      constexpr int PER = (GE::SPAN + RS_THREADS - 1) / RS_THREADS;
+      const int2 *src = reinterpret_cast<const int2 *>(p + 2 * x_first);
+      int2 v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) v[i] = src[min(tid + RS_THREADS * i, GE::SPAN - 1)];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int k = tid + RS_THREADS * i;
+        if (k < GE::SPAN)
+          xs[k + (k >> 3) * 2] = rs_f2{(float)v[i].x * (1.0f / 2147483648.0f), (float)v[i].y * (1.0f / 2147483648.0f)};
+      }
     } else {
       for (int k = tid; k < GE::SPAN; k += RS_THREADS) {
         const long long xi = source(k);
@@ -291,6 +303,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
           b.y = (v[i].z >> 16) | (v[i].w & 0xFFFF0000u);
           reinterpret_cast<uint2 *>(c0)[idx] = a;
           reinterpret_cast<uint2 *>(c1)[idx] = b;
+        }
+      }
+    } else if (interior) { /* 4-byte aligned only (an odd first frame): one frame per load, all in flight */
+      constexpr int NP = GE::SPAN / 2, PER = (NP + RS_THREADS - 1) / RS_THREADS;
+      const unsigned *src = reinterpret_cast<const unsigned *>(p + 2 * x_first);
+      unsigned f0[PER], f1[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int m = min(tid + RS_THREADS * i, NP - 1);
+        f0[i] = src[2 * m];
+        f1[i] = src[2 * m + 1];
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int m = tid + RS_THREADS * i;
+        if (m < NP) {
+          c0[m] = (f0[i] & 0xFFFFu) | (f1[i] << 16);
+          c1[m] = (f0[i] >> 16) | (f1[i] & 0xFFFF0000u);
         }
       }
     } else {
