@@ -2,8 +2,8 @@
  * bl_decode.c — host ingest behind bl_audio_decode().
  *
  * Replaces ref src/decode.c:27-213 (libavformat/libavcodec/libswresample) for
- * the container formats that need no third-party code: RIFF/WAVE integer PCM
- * (16 / 24 / 32 bit) and native FLAC (8 to 32 bit).  It fills struct bl_song as
+ * the container formats that need no third-party code: RIFF/WAVE PCM (8 / 16 / 24 / 32 bit
+ * integer, 32-bit float) and native FLAC (8 to 32 bit).  It fills struct bl_song as
  * fill_song_properties()/bl_audio_decode() do (ref src/decode.c:187-193,
  * 215-349): malloc'd interleaved s16 `sample_array`, nSamples = interleaved
  * count, nb_bytes_per_sample = 2, duration = whole seconds, strdup'd tags
@@ -32,6 +32,7 @@
  * file stays mono.
  */
 #include <ctype.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,6 +71,7 @@ typedef struct {
   int32_t *p32;
   size_t n, cap;
   int wide;
+  int is_float; /* wide only: p32 holds IEEE float bit patterns (RIFF format tag 3) */
   uint32_t bps; /* significant bits of the source */
 } pcm_sink;
 
@@ -209,20 +211,38 @@ static int decode_wav(const uint8_t *d, size_t len, struct bl_song *song, pcm_si
       if (fmt_tag == 0xFFFE && sz >= 26) fmt_tag = le16(body + 24); /* extensible */
       have_fmt = 1;
     } else if (!memcmp(d + pos, "data", 4)) {
-      if (!have_fmt || fmt_tag != 1 || (bits != 16 && bits != 24 && bits != 32) || channels < 1 ||
-          channels > 2 || rate == 0)
+      const int is_float = fmt_tag == 3 && bits == 32; /* IEEE float, full scale +-1 */
+      const int is_pcm = fmt_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32);
+      if (!have_fmt || (!is_float && !is_pcm) || channels < 1 || channels > 2 || rate == 0)
         return BL_UNEXPECTED;
       const uint32_t bytes = bits / 8;
       uint32_t n = sz / bytes;
       n -= n % channels;
       if (n == 0) return BL_UNEXPECTED;
-      sink->bps = bits;
+      /* 8-bit PCM is unsigned; as s16 it is (v - 128) << 8, the conversion every 16-bit path starts from */
+      sink->bps = bits == 8 ? 16 : bits;
       sink->wide = bits > 16 && wants_rate_conversion(rate);
+      sink->is_float = is_float && sink->wide;
       if (sink_reserve(sink, n)) return BL_UNEXPECTED;
       for (uint32_t i = 0; i < n; ++i) {
         const uint8_t *q = body + (size_t)bytes * i;
         int32_t v;
-        if (bits == 16) v = (int16_t)le16(q);
+        if (is_float) {
+          const uint32_t u = le32(q);
+          if (sink->wide) { /* on its way to the rate converter: the float as it is */
+            sink->p32[sink->n++] = (int32_t)u;
+            continue;
+          }
+          /* same-rate FLT -> S16: lrintf(x * 2^15), clipped; not-a-numbers count as silence */
+          float x;
+          memcpy(&x, &u, 4);
+          if (!(x == x) || x > 4.0f || x < -4.0f) x = x > 0 ? 4.0f : (x < 0 ? -4.0f : 0.0f);
+          const long r = lrintf(x * 32768.0f);
+          sink->p16[sink->n++] = (int16_t)(r > 32767 ? 32767 : r < -32768 ? -32768 : r);
+          continue;
+        }
+        if (bits == 8) v = ((int32_t)q[0] - 128) * 256;
+        else if (bits == 16) v = (int16_t)le16(q);
         else if (bits == 24) v = (int32_t)((le16(q + 1) << 8 | q[0]) << 8) >> 8;
         else v = (int32_t)le32(q);
         sink_put(sink, v);
@@ -654,7 +674,7 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
     size_t out_frames = 0;
     const size_t frames = sink.n / (size_t)song->channels;
     rc = bl_resample_to_stereo_s16(sink.wide ? (const void *)sink.p32 : (const void *)sink.p16,
-                                   sink.wide, frames, song->channels, song->sample_rate,
+                                   sink.wide ? (sink.is_float ? 2 : 1) : 0, frames, song->channels, song->sample_rate,
                                    BL_DECODE_RATE, &out, &out_frames);
     if (rc == BL_OK && (out_frames == 0 || out_frames * 2 > (size_t)INT32_MAX)) {
       free(out);

@@ -314,7 +314,13 @@ int bl_resample_to_stereo_s16(const void *in, int in_is_s32, size_t frames, int 
       float *x = (float *)ext + L;
       const float g = (float)M_SQRT1_2;
       for (size_t i = 0; i < frames; ++i) {
-        float v = (float)p[i * (size_t)channels + (size_t)c] * (1.0f / 2147483648.0f);
+        float v;
+        if (in_is_s32 == 2) { /* float source: the sample as it is (not-a-numbers count as silence) */
+          memcpy(&v, &p[i * (size_t)channels + (size_t)c], sizeof v);
+          if (!(v == v) || v > 4.0f || v < -4.0f) v = v > 0 ? 4.0f : (v < 0 ? -4.0f : 0.0f);
+        } else {
+          v = (float)p[i * (size_t)channels + (size_t)c] * (1.0f / 2147483648.0f);
+        }
         if (channels == 1) v *= g;
         x[i] = v;
       }

@@ -30,7 +30,8 @@ void bl_rs_plan_free(bl_rs_plan *f);
 size_t bl_rs_out_frames(const bl_rs_plan *f, size_t frames, size_t *refl);
 
 /* `in`: `frames` interleaved frames of `channels` (1 or 2) channels at `in_rate` Hz, int16, or
- * (in_is_s32) int32 left-justified.  *out: malloc'd interleaved stereo s16 at `out_rate` Hz.
+ * (in_is_s32 = 1) int32 left-justified, or (in_is_s32 = 2) IEEE float with full scale +-1.
+ * *out: malloc'd interleaved stereo s16 at `out_rate` Hz.
  * BL_OK / BL_UNEXPECTED. */
 int bl_resample_to_stereo_s16(const void *in, int in_is_s32, size_t frames, int channels, int in_rate,
                               int out_rate, int16_t **out, size_t *out_frames);

@@ -935,7 +935,8 @@ int bl_amd_resample_host(const void *in, int in_is_s32, size_t frames, int chann
 int bl_amd_ctx_resample_batch_device(bl_amd_ctx *c, const void *d_in, int in_is_s32,
                                      const bl_amd_resample_desc *h_desc, int n_songs, int in_rate,
                                      int16_t *d_out, void *stream) {
-  if (!c || !d_in || !d_out || !h_desc || n_songs <= 0 || in_rate <= 0) return BL_UNEXPECTED;
+  if (!c || !d_in || !d_out || !h_desc || n_songs <= 0 || in_rate <= 0 || (in_is_s32 != 0 && in_is_s32 != 1))
+    return BL_UNEXPECTED; /* float sources: host form only */
   std::lock_guard<std::mutex> lk(c->mu);
   DevGuard dg(c->device);
   if (!dg.ok) return BL_UNEXPECTED;

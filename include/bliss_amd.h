@@ -126,7 +126,8 @@ int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void
  * applies to a file at another rate (a restatement of libswresample's default resampler that
  * reproduces the digests of ref tests/test_decode.c:35-36,55-56), for
  * callers that bring their own decoder.  `in`: interleaved frames of 1 or 2 channels at in_rate
- * Hz, int16, or (in_is_s32) int32 left-justified.  A mono source comes out as two equal
+ * Hz, int16, or (in_is_s32 = 1) int32 left-justified, or — host form only — (in_is_s32 = 2)
+ * float with full scale +-1.  A mono source comes out as two equal
  * channels at gain 1/sqrt(2), as the reference's out layout does.
  *   bl_amd_resample_out_frames: output frames for `frames` of input (0: shorter than the filter);
  *   bl_amd_resample_host: *out is malloc'd (free() it), 2 * *out_frames int16;

@@ -262,6 +262,45 @@ def test_wav_24_and_32_bit(lib, tmp_path):
         assert np.array_equal(pcm, (vals >> (bits - 16)).astype(np.int16))
 
 
+def _wav(path, fmt_tag, channels, rate, bits, raw):
+    fmt = struct.pack("<HHIIHH", fmt_tag, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(raw)) + raw
+    path.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_wav_float_and_8_bit(lib, tmp_path):
+    """RIFF format tag 3 (32-bit float, full scale +-1) and unsigned 8-bit PCM.  Same rate: the
+    sample-format conversions lrintf(x * 2^15) clipped / (v - 128) << 8; another rate: through the
+    converter's float / s16 path like any other source of that width."""
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.uniform(-1.2, 1.2, 2 * 9000), [1.0, -1.0, 0.999999, np.nan, np.inf, -np.inf, 0.0, 3e-5]]).astype(np.float32)
+    p = tmp_path / "f.wav"
+    _wav(p, 3, 2, 22050, 32, x.tobytes())
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["rate"] == 22050 and meta["resampled"] == 0
+    clean = np.where(np.isnan(x), 0.0, np.clip(x, -4.0, 4.0)).astype(np.float32)
+    want = np.clip(np.rint(clean * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+    assert np.array_equal(pcm, want)
+    u8 = rng.integers(0, 256, 2 * 8000).astype(np.uint8)
+    _wav(p, 1, 2, 22050, 8, u8.tobytes())
+    rc, pcm, _ = _decode(lib, p)
+    assert rc == _lib.BL_OK and np.array_equal(pcm, ((u8.astype(np.int32) - 128) * 256).astype(np.int16))
+    # another rate: float WAV == the same samples as left-justified int32 through the float path, when
+    # the floats are exactly k * 2^-31 multiples (then both conversions start from identical floats)
+    k = (rng.integers(-(1 << 23), 1 << 23, 2 * 30000).astype(np.int64) << 8)
+    f = (k.astype(np.float64) / 2147483648.0).astype(np.float32)
+    _wav(p, 3, 2, 44100, 32, f.tobytes())
+    rc, a, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["rate"] == 22050 and meta["resampled"] == 1
+    _wav(p, 1, 2, 44100, 32, k.astype(np.int32).tobytes())
+    rc, b, _ = _decode(lib, p)
+    assert rc == _lib.BL_OK and np.array_equal(a, b)
+    _wav(p, 1, 2, 44100, 8, u8.tobytes())
+    rc, c, _ = _decode(lib, p)
+    import bliss_amd
+    assert rc == _lib.BL_OK and np.array_equal(c, bliss_amd.resample_host(((u8.astype(np.int32) - 128) * 256).astype(np.int16), 2, 44100))
+
+
 def test_malformed_vorbis_comment_lengths(lib, tmp_path):
     """Comment / vendor lengths near 2^32 must not wrap the bounds checks (heap over-read)."""
     s16 = np.zeros(2 * 4096, dtype=np.int64)
