@@ -231,11 +231,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
 
   /* A tile away from the song's edges (all but the first and the last of a stereo song) is
    * staged with 16-byte loads that are all in flight before the first LDS write. */
-  const bool interior = stereo && x_first >= 0 && x_first + GE::SPAN <= N;
+  const bool interior = x_first >= 0 && x_first + GE::SPAN <= N;
   if constexpr (F32) {
     rs_f2 *xs = reinterpret_cast<rs_f2 *>(rs_smem);
     const int32_t *p = static_cast<const int32_t *>(in) + sg.in_off;
-    if (interior && ((reinterpret_cast<size_t>(p + 2 * x_first) & 15) == 0)) {
+    if (stereo && interior && ((reinterpret_cast<size_t>(p + 2 * x_first) & 15) == 0)) {
       constexpr int NV = GE::SPAN / 2, PER = (NV + RS_THREADS - 1) / RS_THREADS; /* 2 frames per load */
       const int4 *src = reinterpret_cast<const int4 *>(p + 2 * x_first);
       int4 v[PER];
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
           *reinterpret_cast<float4 *>(xs + k + (k >> 3) * 2) = w;
         }
       }
-    } else if (interior) { /* 8-byte aligned only (an odd first frame): one frame per load, all in flight */
+    } else if (stereo && interior) { /* 8-byte aligned only (an odd first frame): one frame per load, all in flight */
       constexpr int PER = (GE::SPAN + RS_THREADS - 1) / RS_THREADS;
       const int2 *src = reinterpret_cast<const int2 *>(p + 2 * x_first);
       int2 v[PER];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
     unsigned *c0 = reinterpret_cast<unsigned *>(rs_smem);
     unsigned *c1 = c0 + GE::SPAN / 2;
     const int16_t *p = static_cast<const int16_t *>(in) + sg.in_off;
-    if (interior && ((reinterpret_cast<size_t>(p + 2 * x_first) & 15) == 0)) {
+    if (stereo && interior && ((reinterpret_cast<size_t>(p + 2 * x_first) & 15) == 0)) {
       constexpr int NV = GE::SPAN / 4, PER = (NV + RS_THREADS - 1) / RS_THREADS; /* 4 frames per load */
       const uint4 *src = reinterpret_cast<const uint4 *>(p + 2 * x_first);
       uint4 v[PER];
@@ -305,7 +305,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_resample_1p(const void *__restri
           reinterpret_cast<uint2 *>(c1)[idx] = b;
         }
       }
-    } else if (interior) { /* 4-byte aligned only (an odd first frame): one frame per load, all in flight */
+    } else if (!stereo && interior && ((reinterpret_cast<size_t>(p + x_first) & 15) == 0)) {
+      /* mono: 8 frames per load, up-mixed (Q15 1/sqrt(2)) into both channels */
+      constexpr int NV = GE::SPAN / 8, PER = (NV + RS_THREADS - 1) / RS_THREADS;
+      const uint4 *src = reinterpret_cast<const uint4 *>(p + x_first);
+      uint4 v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) v[i] = src[min(tid + RS_THREADS * i, NV - 1)];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + RS_THREADS * i;
+        if (idx < NV) {
+          const unsigned w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+          unsigned o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int lo = (((int)(short)(w[k] & 0xFFFFu)) * 23170 + 16384) >> 15;
+            const int hi = (((int)(short)(w[k] >> 16)) * 23170 + 16384) >> 15;
+            o[k] = ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16);
+          }
+          reinterpret_cast<uint4 *>(c0)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+          reinterpret_cast<uint4 *>(c1)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    } else if (stereo && interior) { /* 4-byte aligned only (an odd first frame): one frame per load, all in flight */
       constexpr int NP = GE::SPAN / 2, PER = (NP + RS_THREADS - 1) / RS_THREADS;
       const unsigned *src = reinterpret_cast<const unsigned *>(p + 2 * x_first);
       unsigned f0[PER], f1[PER];
@@ -502,8 +525,7 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
     const int16_t *p = static_cast<const int16_t *>(in) + sg.in_off;
     const int nq = (rfr + 2 + 3) / 4; /* 16-byte units (4 frames) per region */
     constexpr int PFU = 2;            /* units per lane and region: adv + L + 2 <= 512 frames */
-    const bool can_vector = stereo && ((reinterpret_cast<size_t>(p) & 15) == 0) && (adv % 4 == 0) &&
-                            nq <= 64 * PFU;
+    const bool can_vector = ((reinterpret_cast<size_t>(p) & 15) == 0) && (adv % 4 == 0) && nq <= 64 * PFU;
     /* a tile away from the song's edges is fetched with 16-byte loads into registers while the
      * previous tile is being computed */
     auto interior = [&](int tile) -> bool {
@@ -512,14 +534,27 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
     };
     uint4 pf[RSP_REG][PFU];
     auto prefetch = [&](int tile) {
-      const uint4 *src = reinterpret_cast<const uint4 *>(p + 2 * x_first_of(tile));
+      if (stereo) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p + 2 * x_first_of(tile));
 #pragma unroll
-      for (int k = 0; k < RSP_REG; ++k) {
-        const int m = wave + RSP_WAVES * k;
+        for (int k = 0; k < RSP_REG; ++k) {
+          const int m = wave + RSP_WAVES * k;
 #pragma unroll
-        for (int u = 0; u < PFU; ++u) {
-          /* unconditional (clamped): a load under a lane mask makes the compiler wait for it at once */
-          pf[k][u] = src[(m * adv) / 4 + min(lane + 64 * u, nq - 1)];
+          for (int u = 0; u < PFU; ++u) {
+            /* unconditional (clamped): a load under a lane mask makes the compiler wait for it at once */
+            pf[k][u] = src[(m * adv) / 4 + min(lane + 64 * u, nq - 1)];
+          }
+        }
+      } else { /* mono: the same four frames are 8 bytes */
+        const uint2 *src = reinterpret_cast<const uint2 *>(p + x_first_of(tile));
+#pragma unroll
+        for (int k = 0; k < RSP_REG; ++k) {
+          const int m = wave + RSP_WAVES * k;
+#pragma unroll
+          for (int u = 0; u < PFU; ++u) {
+            const uint2 v = src[(m * adv) / 4 + min(lane + 64 * u, nq - 1)];
+            pf[k][u] = make_uint4(v.x, v.y, 0u, 0u);
+          }
         }
       }
     };
@@ -533,10 +568,20 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
           if (q < nq) {
             const uint4 v = pf[k][u];
             unsigned *d0 = c0 + m * R + 2 * q, *d1 = c1 + m * R + 2 * q;
-            d0[0] = (v.x & 0xFFFFu) | (v.y << 16);
-            d0[1] = (v.z & 0xFFFFu) | (v.w << 16);
-            d1[0] = (v.x >> 16) | (v.y & 0xFFFF0000u);
-            d1[1] = (v.z >> 16) | (v.w & 0xFFFF0000u);
+            if (stereo) {
+              d0[0] = (v.x & 0xFFFFu) | (v.y << 16);
+              d0[1] = (v.z & 0xFFFFu) | (v.w << 16);
+              d1[0] = (v.x >> 16) | (v.y & 0xFFFF0000u);
+              d1[1] = (v.z >> 16) | (v.w & 0xFFFF0000u);
+            } else { /* up-mix (Q15 1/sqrt(2)) into both channels */
+              const unsigned w[2] = {v.x, v.y};
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int lo = (((int)(short)(w[h] & 0xFFFFu)) * 23170 + 16384) >> 15;
+                const int hi = (((int)(short)(w[h] >> 16)) * 23170 + 16384) >> 15;
+                d0[h] = d1[h] = ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16);
+              }
+            }
           }
         }
       }
