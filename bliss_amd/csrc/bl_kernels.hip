@@ -962,9 +962,10 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
  * workgroups' compute waves).  The wave's slice holds five blocks of 256 filtered samples as a
  * ring: a round filters the 1 024 new samples (16 outputs per lane) into the four positions the
  * previous round has released and finds the block it shares with the previous round where that
- * round left it — nothing is copied.  The transposes and partner rows of window g use the place
- * of block g, which every window has finished reading by then; the carried block is nobody's
- * block g.  Each lane normalises the 32 samples its 16 outputs read from its own loads: no
+ * round left it — nothing is copied.  The transposes of window g use the place of block g, which
+ * every window has finished reading by then; the carried block is nobody's block g.  The partner
+ * values of the real-input split come through DPP (row mirror + rotation), not through LDS: an LDS
+ * round trip on the wave's critical path costs more than the moves.  Each lane normalises the 32 samples its 16 outputs read from its own loads: no
  * cross-lane shift, hence no lane 0 that would need the previous round's lane 63.  The first
  * round of a run is preceded by a short pass that filters the one block it cannot inherit.
  * Rounds, hand-over to the summing wave, DFT and power terms are those of k_env_windows2;
@@ -1057,9 +1058,10 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
   const int mean = st.mean;
   const double rcp = st.rcp, rcp_lo = st.rcp_lo;
   const int r0 = run_begin(u0 + wave), r1 = run_begin(u0 + wave + 1);
-  c2d w1r[16];
+  constexpr int EV3_W1_REGS = 13; /* pass-1 twiddles 1..12 in registers, 13..15 from LDS */
+  c2d w1r[EV3_W1_REGS];
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) {
+  for (int k1 = 1; k1 < EV3_W1_REGS; ++k1) {
     w1r[k1] = tw256[k1 * 16 + l];
     asm volatile("" : "+v"(w1r[k1].re), "+v"(w1r[k1].im));
   }
@@ -1180,8 +1182,10 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
     ev2_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
     bl_fft16(re, im);
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1)
-      bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w1r[k1].re, w1r[k1].im);
+    for (int k1 = 1; k1 < 16; ++k1) {
+      const c2d w = k1 < EV3_W1_REGS ? w1r[k1] : tw256[k1 * 16 + l];
+      bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w.re, w.im);
+    }
     double *xg = blk_a; /* [16][18] doubles, re then im */
     const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
 #pragma unroll
@@ -1197,17 +1201,19 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
     for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
     ev2_wave_sync();
     bl_fft16(re, im);
-    double2 *pg = reinterpret_cast<double2 *>(blk_a); /* partner half rows, 9 pairs per lane row */
-#pragma unroll
-    for (int k0 = 8; k0 < 16; ++k0)
-      pg[l * 9 + (k0 - 8)] = make_double2(re[bl_pos16(k0)], im[bl_pos16(k0)]);
-    ev2_wave_sync();
+    /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16 —
+     * a mirror of the 16-lane row followed by a rotation by one, two DPP moves per dword and no LDS
+     * round trip; lane 0 is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
     double own[8], mir[8];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
-      const int sl = bl_partner_slot(l, k0);
-      double pr = re[bl_pos16(0)], pi = im[bl_pos16(0)];
-      if (sl >= 0) { const double2 v = pg[(sl >> 3) * 9 + (sl & 7)]; pr = v.x; pi = v.y; }
+      const double sr = re[bl_pos16(15 - k0)], si = im[bl_pos16(15 - k0)];
+      double pr = bl_dpp_f64<0x121>(bl_dpp_f64<0x140>(sr)); /* row_mirror, then row_ror:1 */
+      double pi = bl_dpp_f64<0x121>(bl_dpp_f64<0x140>(si));
+      const double zr = k0 ? re[bl_pos16(16 - k0)] : re[bl_pos16(0)];
+      const double zi = k0 ? im[bl_pos16(16 - k0)] : im[bl_pos16(0)];
+      pr = l == 0 ? zr : pr;
+      pi = l == 0 ? zi : pi;
       bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
                                       own[k0], mir[k0]);
     }
