@@ -384,6 +384,14 @@ typedef bl_c2<bl_f2> c2p; /* a complex number per frame of the pair */
  * that share a 32-lane store group land on disjoint banks */
 #define BL_FREQ_SROW 264
 
+/* cross-lane move of a pair of floats through DPP (two 32-bit moves); CTRL 0x140 = row_mirror,
+ * 0x120 + n = row_ror:n inside each 16-lane row */
+template <int CTRL> __device__ __forceinline__ bl_f2 bl_dpp_f2(bl_f2 v) {
+  const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v.x), CTRL, 0xF, 0xF, true);
+  const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), CTRL, 0xF, 0xF, true);
+  return (bl_f2){__int_as_float(x), __int_as_float(y)};
+}
+
 template <bool STEREO>
 __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm, const bl_dsong &sg,
                                                  const bl_tables &tb, float *spectrum) {
@@ -499,26 +507,26 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     bl_wave_sync();
     fetch(f + BL_FREQ_FPI, 2);
     bl_fft16(re, im);
-#pragma unroll
-    for (int k0 = 8; k0 < 16; ++k0) {
-      c2p v; v.re = re[bl_pos16(k0)]; v.im = im[bl_pos16(k0)];
-      gx[l * 9 + (k0 - 8)] = v; /* row stride 9: with 8, the eight lanes of a b128 store group share four banks */
-    }
-    bl_wave_sync();
     fetch(f + BL_FREQ_FPI, 3);
+    /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16,
+     * fetched by a mirror of the 16-lane row and a rotation by one (DPP), not through LDS; lane 0
+     * is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
     bl_f2 own[8], mir[8];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
-      const int sl = bl_partner_slot(l, k0);
-      bl_f2 pr = re[bl_pos16(0)], pi = im[bl_pos16(0)];
-      if (sl >= 0) { const c2p v = gx[(sl >> 3) * 9 + (sl & 7)]; pr = v.re; pi = v.im; }
+      bl_f2 pr = bl_dpp_f2<0x121>(bl_dpp_f2<0x140>(re[bl_pos16(15 - k0)]));
+      bl_f2 pi = bl_dpp_f2<0x121>(bl_dpp_f2<0x140>(im[bl_pos16(15 - k0)]));
+      const bl_f2 zr = k0 ? re[bl_pos16(16 - k0)] : re[bl_pos16(0)];
+      const bl_f2 zi = k0 ? im[bl_pos16(16 - k0)] : im[bl_pos16(0)];
+      pr = l == 0 ? zr : pr;
+      pi = l == 0 ? zi : pi;
       const c2f w = tw512[l + 16 * k0];
       c2p wp; wp.re = (bl_f2){w.re, w.re}; wp.im = (bl_f2){w.im, w.im};
       bl_fft512_power1<bl_f2>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, wp, own[k0], mir[k0]);
     }
     const bl_f2 mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
     const bl_f2 mid = bl_fma(mr, mr, mi * mi);
-    bl_wave_sync(); /* partner rows are consumed: the wave's exchange space becomes `stage` */
+    /* the transposed rows were read before the second pass: the wave's exchange space is free for `stage` */
     /* ref :88-93: re*re + im*im of bin d, for d = 1..255 */
     float *sa = stage + (2 * gl) * BL_FREQ_SROW, *sb = sa + BL_FREQ_SROW;
 #pragma unroll
