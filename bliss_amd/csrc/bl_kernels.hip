@@ -686,6 +686,15 @@ template <int CTRL> __device__ __forceinline__ double bl_dpp_f64(double v) {
   return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
+/* the same with a value for the lanes that have no source (they keep `old`) */
+template <int CTRL> __device__ __forceinline__ double bl_dpp_f64_old(double old, double v) {
+  const unsigned long long b = __double_as_longlong(v), o = __double_as_longlong(old);
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)(o & 0xFFFFFFFFull), (int)(unsigned)(b & 0xFFFFFFFFull),
+                                             CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+  return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 /* LDS slot of tile-local sample j of a compute wave: two pads after every 20 samples make
  * the per-lane stride 22 doubles (44 banks: conflict-free 16-byte stores per 8-lane group)
  * and keep every even sample 16-byte aligned, so that the (re, im) = (y[2m], y[2m+1]) pairs
@@ -1102,23 +1111,18 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
 
   /* lane ln owns outputs 16 ln .. 16 ln + 15 of the round's 1 024 new samples and loads the 32
    * samples they read (four 16-byte loads), plus the sample that starts its zero-state output;
-   * fetched one round ahead, unconditionally (clamped addresses, values zeroed by a select) */
+   * fetched one round ahead.  The loads are unconditional and the addresses clamped into the song:
+   * what lies beyond its last window (or belongs to a round this wave does not run) only reaches
+   * windows that are never summed, so any sample will do there — no select, which would also put
+   * copies of these loop-carried registers at the loop latch. */
   uint4 pre[4];
   short preh;
+  const int last8 = max(n_used - 8, 0);
   auto fetch = [&](int rho_) {
-    const bool live = rho_ < r1;
     const int base = 1024 * rho_ + 240 + 16 * ln; /* first input = first output - 16 */
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i0 = base + 8 * u;
-      const bool ok = live && i0 + 8 <= n_used;
-      const uint4 v = *reinterpret_cast<const uint4 *>(p + (ok ? i0 : 0));
-      pre[u] = ok ? v : make_uint4(0, 0, 0, 0);
-    }
-    const int ih = 1024 * rho_ + 256 * g + l;
-    const bool okh = live && ih < n_used;
-    const short vh = p[okh ? ih : 0];
-    preh = okh ? vh : (short)0;
+    for (int u = 0; u < 4; ++u) pre[u] = *reinterpret_cast<const uint4 *>(p + min(base + 8 * u, last8));
+    preh = p[min(1024 * rho_ + 256 * g + l, n_used - 1)];
   };
   fetch(r0);
   for (int s = 0; s < steps; ++s) {
@@ -1216,12 +1220,12 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
       const double sr = re[bl_pos16(15 - k0)], si = im[bl_pos16(15 - k0)];
-      double pr = bl_dpp_f64<0x121>(bl_dpp_f64<0x140>(sr)); /* row_mirror, then row_ror:1 */
-      double pi = bl_dpp_f64<0x121>(bl_dpp_f64<0x140>(si));
       const double zr = k0 ? re[bl_pos16(16 - k0)] : re[bl_pos16(0)];
       const double zi = k0 ? im[bl_pos16(16 - k0)] : im[bl_pos16(0)];
-      pr = l == 0 ? zr : pr;
-      pi = l == 0 ? zi : pi;
+      /* row_mirror, then a shift by one inside the row: lane 0 has no source there and keeps
+       * `old`, which is what it needs instead — its own register */
+      const double pr = bl_dpp_f64_old<0x111>(zr, bl_dpp_f64<0x140>(sr));
+      const double pi = bl_dpp_f64_old<0x111>(zi, bl_dpp_f64<0x140>(si));
       bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
                                       own[k0], mir[k0]);
     }
