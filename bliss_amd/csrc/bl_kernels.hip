@@ -391,6 +391,12 @@ template <int CTRL> __device__ __forceinline__ bl_f2 bl_dpp_f2(bl_f2 v) {
   const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), CTRL, 0xF, 0xF, true);
   return (bl_f2){__int_as_float(x), __int_as_float(y)};
 }
+/* the same with a value for the lanes that have no source (they keep `old`) */
+template <int CTRL> __device__ __forceinline__ bl_f2 bl_dpp_f2_old(bl_f2 old, bl_f2 v) {
+  const int x = __builtin_amdgcn_update_dpp(__float_as_int(old.x), __float_as_int(v.x), CTRL, 0xF, 0xF, false);
+  const int y = __builtin_amdgcn_update_dpp(__float_as_int(old.y), __float_as_int(v.y), CTRL, 0xF, 0xF, false);
+  return (bl_f2){__int_as_float(x), __int_as_float(y)};
+}
 
 template <bool STEREO>
 __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm, const bl_dsong &sg,
@@ -509,17 +515,17 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     bl_fft16(re, im);
     fetch(f + BL_FREQ_FPI, 3);
     /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16,
-     * fetched by a mirror of the 16-lane row and a rotation by one (DPP), not through LDS; lane 0
+     * fetched by a mirror of the 16-lane row and a shift by one (DPP), not through LDS; lane 0
      * is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
     bl_f2 own[8], mir[8];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
-      bl_f2 pr = bl_dpp_f2<0x121>(bl_dpp_f2<0x140>(re[bl_pos16(15 - k0)]));
-      bl_f2 pi = bl_dpp_f2<0x121>(bl_dpp_f2<0x140>(im[bl_pos16(15 - k0)]));
       const bl_f2 zr = k0 ? re[bl_pos16(16 - k0)] : re[bl_pos16(0)];
       const bl_f2 zi = k0 ? im[bl_pos16(16 - k0)] : im[bl_pos16(0)];
-      pr = l == 0 ? zr : pr;
-      pi = l == 0 ? zi : pi;
+      /* row_mirror, then a shift by one inside the row: lane 0 has no source there and keeps `old`,
+       * its own register — which is what it needs */
+      const bl_f2 pr = bl_dpp_f2_old<0x111>(zr, bl_dpp_f2<0x140>(re[bl_pos16(15 - k0)]));
+      const bl_f2 pi = bl_dpp_f2_old<0x111>(zi, bl_dpp_f2<0x140>(im[bl_pos16(15 - k0)]));
       const c2f w = tw512[l + 16 * k0];
       c2p wp; wp.re = (bl_f2){w.re, w.re}; wp.im = (bl_f2){w.im, w.im};
       bl_fft512_power1<bl_f2>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, wp, own[k0], mir[k0]);
