@@ -561,12 +561,19 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     float acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = accv[lane + 64 * q];
+    if (n_live >= 8) { /* every iteration but a song's last: no per-frame test (hipcc makes selects of it) */
 #pragma unroll
-    for (int fr = 0; fr < 8; ++fr)
-      if (fr < n_live) { /* wave-uniform */
+      for (int fr = 0; fr < 8; ++fr)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] += sv[q][fr];
-      }
+    } else {
+#pragma unroll
+      for (int fr = 0; fr < 8; ++fr)
+        if (fr < n_live) { /* wave-uniform */
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += sv[q][fr];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) accv[lane + 64 * q] = acc[q];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
