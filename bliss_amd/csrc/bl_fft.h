@@ -74,26 +74,49 @@ template <typename T> BL_HD void bl_fft16(T (&re)[16], T (&im)[16]) {
 #pragma unroll
   for (int n0 = 0; n0 < 4; ++n0)
     bl_r4(re[n0], im[n0], re[4 + n0], im[4 + n0], re[8 + n0], im[8 + n0], re[12 + n0], im[12 + n0]);
-  /* element 4*k1 + n0 now holds A[n0][k1]; multiply by W16^(n0*k1) */
-  /* exponent 1: (n0,k1) = (1,1) -> idx 5 */
-  bl_cmul(re[5], im[5], C1, -S1);
-  /* exponent 2: (1,2) idx 9, (2,1) idx 6 : *(R - iR) */
-  { T a = re[9], b = im[9]; re[9] = R * (a + b); im[9] = R * (b - a); }
-  { T a = re[6], b = im[6]; re[6] = R * (a + b); im[6] = R * (b - a); }
-  /* exponent 3: (1,3) idx 13, (3,1) idx 7 */
-  bl_cmul(re[13], im[13], S1, -C1);
-  bl_cmul(re[7], im[7], S1, -C1);
-  /* exponent 4: (2,2) idx 10 : * (-i) */
-  { T a = re[10], b = im[10]; re[10] = b; im[10] = -a; }
-  /* exponent 6: (2,3) idx 14, (3,2) idx 11 : *(-R - iR) */
-  { T a = re[14], b = im[14]; re[14] = R * (b - a); im[14] = -(R * (a + b)); }
-  { T a = re[11], b = im[11]; re[11] = R * (b - a); im[11] = -(R * (a + b)); }
-  /* exponent 9: (3,3) idx 15 : * (-C1 + i S1) */
-  bl_cmul(re[15], im[15], -C1, S1);
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1)
-    bl_r4(re[4 * k1], im[4 * k1], re[4 * k1 + 1], im[4 * k1 + 1], re[4 * k1 + 2], im[4 * k1 + 2],
-          re[4 * k1 + 3], im[4 * k1 + 3]);
+  /* element 4*k1 + n0 now holds A[n0][k1]; it wants W16^(n0*k1) before the second pass.  The
+   * general twiddles are multiplied here; the four that are R (1 -+ i) or R (-1 - i) are left as
+   * their unscaled sums and the factor R goes into the second pass's additions as an fma (one
+   * rounding instead of two, eight multiplications fewer) */
+  bl_cmul(re[5], im[5], C1, -S1);   /* exponent 1: (n0,k1) = (1,1) */
+  bl_cmul(re[13], im[13], S1, -C1); /* exponent 3: (1,3) */
+  bl_cmul(re[7], im[7], S1, -C1);   /* exponent 3: (3,1) */
+  bl_cmul(re[15], im[15], -C1, S1); /* exponent 9: (3,3) */
+  /* exponent 2, (1,2) idx 9 and (2,1) idx 6: R * ((a + b) + i (b - a)) */
+  { T a = re[9], b = im[9]; re[9] = a + b; im[9] = b - a; }
+  { T a = re[6], b = im[6]; re[6] = a + b; im[6] = b - a; }
+  /* exponent 6, (2,3) idx 14 and (3,2) idx 11: R * ((b - a) - i (a + b)) */
+  { T a = re[14], b = im[14]; re[14] = b - a; im[14] = -(a + b); }
+  { T a = re[11], b = im[11]; re[11] = b - a; im[11] = -(a + b); }
+  /* k1 = 0: no twiddles */
+  bl_r4(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
+  { /* k1 = 1: c = R * (re[6], im[6]) */
+    const T ar = re[4], ai = im[4], br = re[5], bi = im[5], cr = re[6], ci = im[6], dr = re[7], di = im[7];
+    const T t0r = bl_fma(R, cr, ar), t0i = bl_fma(R, ci, ai), t1r = bl_fma(-R, cr, ar), t1i = bl_fma(-R, ci, ai);
+    const T t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
+    re[4] = t0r + t2r; im[4] = t0i + t2i;
+    re[6] = t0r - t2r; im[6] = t0i - t2i;
+    re[5] = t1r + t3i; im[5] = t1i - t3r;
+    re[7] = t1r - t3i; im[7] = t1i + t3r;
+  }
+  { /* k1 = 2: b = R * (re[9], im[9]), c = -i * (re[10], im[10]), d = R * (re[11], im[11]) */
+    const T ar = re[8], ai = im[8], cr = im[10], ci = -re[10];
+    const T t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+    const T u2r = re[9] + re[11], u2i = im[9] + im[11], u3r = re[9] - re[11], u3i = im[9] - im[11];
+    re[8] = bl_fma(R, u2r, t0r);   im[8] = bl_fma(R, u2i, t0i);
+    re[10] = bl_fma(-R, u2r, t0r); im[10] = bl_fma(-R, u2i, t0i);
+    re[9] = bl_fma(R, u3i, t1r);   im[9] = bl_fma(-R, u3r, t1i);
+    re[11] = bl_fma(-R, u3i, t1r); im[11] = bl_fma(R, u3r, t1i);
+  }
+  { /* k1 = 3: c = R * (re[14], im[14]) */
+    const T ar = re[12], ai = im[12], br = re[13], bi = im[13], cr = re[14], ci = im[14], dr = re[15], di = im[15];
+    const T t0r = bl_fma(R, cr, ar), t0i = bl_fma(R, ci, ai), t1r = bl_fma(-R, cr, ar), t1i = bl_fma(-R, ci, ai);
+    const T t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
+    re[12] = t0r + t2r; im[12] = t0i + t2i;
+    re[14] = t0r - t2r; im[14] = t0i - t2i;
+    re[13] = t1r + t3i; im[13] = t1i - t3r;
+    re[15] = t1r - t3i; im[15] = t1i + t3r;
+  }
   /* element 4*k1 + k0 holds X[k1 + 4*k0] */
 }
 
