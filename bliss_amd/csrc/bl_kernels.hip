@@ -565,7 +565,12 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
 #pragma unroll
       for (int fr = 0; fr < 8; ++fr)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += sv[q][fr];
+        for (int q = 0; q < 4; ++q) {
+          acc[q] += sv[q][fr];
+          /* one v_add_f32 each: paired into v_pk_add_f32 the operands need more moves than the
+           * pairing saves, and this is the stretch during which the wave holds the baton */
+          asm volatile("" : "+v"(acc[q]));
+        }
     } else {
 #pragma unroll
       for (int fr = 0; fr < 8; ++fr)
