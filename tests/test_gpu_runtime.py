@@ -107,6 +107,38 @@ print(json.dumps({"enqueue": t1 - t0, "total": t2 - t0}))
     assert t["enqueue"] < 0.5 * t["total"], t     # ~14 ms of kernels behind a sub-millisecond enqueue
 
 
+def test_both_envelope_kernels_agree(tmp_path):
+    """k_env_windows3 (contiguous runs, ring of blocks) and its predecessor k_env_windows2 (selected by
+    BL_AMD_ENV_OLD=1 in a fresh process) give identical records and identical window energies: mixed
+    lengths and channel counts, a song shorter than one run, few songs (several workgroups per song)."""
+    code = r'''
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+import torch, bliss_amd
+lengths = [22050 * 2 * 9 + 8 * i for i in range(5)] + [5120, 6000, 22050 * 1 * 40, 44100 * 2 * 33]
+chans = [2, 2, 2, 2, 2, 2, 1, 1, 2]
+c = bliss_amd.DeviceCorpus(lengths, chans, 9)
+c.synth(seed_base=900, sample_rate=22050)
+c.analyze(); r = c.fetch()
+np.save(sys.argv[1], r)
+lib = bliss_amd.load()
+import ctypes as C
+buf = (C.c_float * 400000)()
+n = lib.bl_amd_last_energies(buf, 400000)
+print(n, hashlib.md5(bytes(buf)[: 4 * max(n, 0)]).hexdigest())
+''' % ROOT
+    outs = {}
+    for tag, env in (("new", {}), ("old", {"BL_AMD_ENV_OLD": "1"})):
+        f = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), text=True,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = (np.load(f), r.stdout.strip().splitlines()[-1])
+    _same(outs["new"][0], outs["old"][0])
+    assert outs["new"][1] == outs["old"][1] and not outs["new"][1].startswith("0 "), outs
+
+
 def test_host_transfer_modes_and_s32(gpu_lib, oracle):
     songs = _songs(oracle, 4300, 9)
     pcms, chans, durs = [p for p, _, _ in songs], [c for _, c, _ in songs], [d for _, _, d in songs]
