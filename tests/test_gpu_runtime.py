@@ -126,7 +126,13 @@ lib = bliss_amd.load()
 import ctypes as C
 buf = (C.c_float * 400000)()
 n = lib.bl_amd_last_energies(buf, 400000)
-print(n, hashlib.md5(bytes(buf)[: 4 * max(n, 0)]).hexdigest())
+e = np.frombuffer(bytes(buf), dtype=np.float32)[: max(n, 0)]
+# a song owns nb_frames slots and fills the first n_windows of them; the other two are never written
+valid, off = [], 0
+for nb, nw in zip(r["nb_frames"], r["n_windows"]):
+    valid.append(e[off:off + int(nw)]); off += int(nb)
+assert off == n
+print(n, hashlib.md5(np.concatenate(valid).tobytes()).hexdigest())
 ''' % ROOT
     outs = {}
     for tag, env in (("new", {}), ("old", {"BL_AMD_ENV_OLD": "1"})):
