@@ -628,34 +628,41 @@ __global__ __launch_bounds__(RSP_THREADS) void k_resample_pm(const void *__restr
       fetched = tile + 1 < tile_end && interior(tile + 1);
       if (fetched) prefetch(tile + 1);
 
-      int base = base0, idx = idx0;
-      for (int r = wave; r < pc; r += RSP_WAVES) {
-        /* lane j takes the phase's j-th pair of taps from the table; v_readlane hands it to
-         * the whole wave */
-        const unsigned vp = tp[r * (L / 2 + 1) + min(lane, L / 2)];
-        const unsigned *a0 = c0 + lane * R + (base >> 1), *a1 = c1 + lane * R + (base >> 1);
-        /* all of the window's reads go out before the first multiply (left alone, the compiler
-         * issues them four at a time and waits for each group) */
-        unsigned xa[L / 2 + 1], xb[L / 2 + 1];
+      /* Two consecutive phases per pass: their windows start 2 or 3 frames apart (adv / phases), so
+       * one read of L / 2 + 3 dwords per channel serves both — the second phase uses the same
+       * registers one or two dwords further on (its tap pairs in the table already have the parity
+       * of its own start).  Lane j takes a phase's j-th pair of taps from the table; v_readlane
+       * hands it to the whole wave. */
+      constexpr int NP = L / 2 + 1;
+      for (int pr = wave; 2 * pr < pc; pr += RSP_WAVES) {
+        const int ra = 2 * pr, rb = min(ra + 1, pc - 1); /* rb == ra: the odd phase out at the end */
+        const int da = ((ra * adv) / pc + delta) >> 1, diff = (((rb * adv) / pc + delta) >> 1) - da;
+        const unsigned vpa = tp[ra * NP + min(lane, L / 2)], vpb = tp[rb * NP + min(lane, L / 2)];
+        const unsigned *a0 = c0 + lane * R + da, *a1 = c1 + lane * R + da;
+        /* all of the reads go out before the first multiply (left alone, the compiler issues them
+         * four at a time and waits for each group) */
+        unsigned xa[NP + 2], xb[NP + 2];
 #pragma unroll
-        for (int j = 0; j <= L / 2; ++j) {
+        for (int j = 0; j < NP + 2; ++j) {
           xa[j] = a0[j];
           xb[j] = a1[j];
         }
 #pragma unroll
-        for (int j = 0; j <= L / 2; ++j) asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));
-        int acc0 = 1 << 14, acc1 = 1 << 14;
+        for (int j = 0; j < NP + 2; ++j) asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));
+        auto phase = [&](int r, unsigned vp, const unsigned *wa, const unsigned *wb) {
+          int acc0 = 1 << 14, acc1 = 1 << 14;
 #pragma unroll
-        for (int j = 0; j <= L / 2; ++j) {
-          const rs_s2 cv = __builtin_bit_cast(rs_s2, (unsigned)__builtin_amdgcn_readlane((int)vp, j));
-          acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(rs_s2, xa[j]), cv, acc0, false);
-          acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(rs_s2, xb[j]), cv, acc1, false);
-        }
-        ob[r + pc * lane] =
-            ((unsigned)rs_clip16(acc0 >> 15) & 0xFFFFu) | ((unsigned)rs_clip16(acc1 >> 15) << 16);
-        idx += idx_step;
-        base += base_step;
-        if (idx >= pc) { idx -= pc; ++base; }
+          for (int j = 0; j < NP; ++j) {
+            const rs_s2 cv = __builtin_bit_cast(rs_s2, (unsigned)__builtin_amdgcn_readlane((int)vp, j));
+            acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(rs_s2, wa[j]), cv, acc0, false);
+            acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(rs_s2, wb[j]), cv, acc1, false);
+          }
+          ob[r + pc * lane] =
+              ((unsigned)rs_clip16(acc0 >> 15) & 0xFFFFu) | ((unsigned)rs_clip16(acc1 >> 15) << 16);
+        };
+        phase(ra, vpa, xa, xb);
+        if (diff == 1) phase(rb, vpb, xa + 1, xb + 1);      /* wave-uniform */
+        else if (diff == 2) phase(rb, vpb, xa + 2, xb + 2);
       }
       __syncthreads();
       const long long n0 = (long long)tile * T;
