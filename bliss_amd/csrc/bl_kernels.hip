@@ -420,7 +420,7 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
   if (tid == 0) relay[0] = 0;
   __syncthreads();
 
-  c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* partner rows alias the transpose */
+  c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* the transpose buffer of this 16-lane group */
   float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [8][BL_FREQ_SROW] */
   /* one iteration ahead: 32 unconditional loads per lane (frame indices clamped into the song;
    * a frame past the end is transformed like any other and simply not added), so the HBM
