@@ -13,10 +13,13 @@ Workload: BASELINE.json configs[2] shape — 3-minute 44.1 kHz s16 stereo buffer
 does; the count used is printed in config.workload).  Songs are sharded by index across
 ranks (weak scaling, no data-path collective other than the vector all-gather).
 
-Launch: `python bench.py` (1 GPU) or
+Launch: `python bench.py --gpus N --steps K --warmup W` — for N > 1 (or with `--launch`) the
+script starts its own N ranks, one per GPU, under torch.distributed.run on 127.0.0.1 and passes
+their output through — or the launcher form the driver uses,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
  --master-port P bench.py --gpus N --steps K --warmup W`.
-Rank 0 prints ONE JSON line.
+Either way rank 0 prints ONE JSON line.  `--plumbing-only` runs launch, process group (gloo),
+sharding and the all-gather on stand-in vectors without a GPU: the CPU test of this plumbing.
 """
 import argparse
 import ctypes as C
@@ -169,6 +172,130 @@ def verify_songs(res, picks, seed_first, seconds):
     return ok, details
 
 
+F64_ISSUE_TWAVEINSTR_S = 0.56     # measured f64 VALU issue rate, T wave-instr/s (tools/ubench_rate.hip; = 71.5 TF as FMA)
+# f64 wave-instructions per window the arithmetic needs, by FIR mode: mode 0 the
+# reference's unfused FIR (25 ops/output) and two-op normalisation; 1: 17 ops/output; 2: no normalisation
+F64_FLOOR_INSTR_PER_WINDOW = {0: 289, 1: 255, 2: 247}
+
+
+def _committed_profile(songs, song_samples):
+    """Counters of the newest committed PMC profile (profiles/*_hbm_traffic.json): HBM bytes per
+    launch scaled to this launch, VALU instructions per window, busy fractions, the whole step's
+    traffic ratio.  Never raises: what is missing is None and `error` says why."""
+    import glob
+    out = {"traffic": None, "error": None, "file": None}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        out["error"] = "no profiles/*_hbm_traffic.json committed"
+        return out
+    out["file"] = os.path.relpath(files[-1], ROOT)
+    try:
+        tj = json.load(open(files[-1]))
+        kernels = tj["kernels"]
+        tk = kernels.get("k_env_windows3") or kernels["k_env_windows2"]
+        scale = song_samples / 15876000.0
+        out["traffic"] = tk["hbm_bytes_per_song"] * songs * scale
+        out["git_head"] = tj.get("git_head")
+        out["fir_mode"] = tj.get("fir_mode")
+        out["valu_busy_frac"], out["lds_busy_frac"] = tk.get("valu_busy_frac"), tk.get("lds_busy_frac")
+        psongs = tj.get("songs") or 0
+        if tk.get("SQ_INSTS_VALU") and psongs:
+            out["valu_instr_per_window"] = tk["SQ_INSTS_VALU"] / (psongs * 62012.0)
+        step = [kernels[k]["hbm_bytes"] for k in ("k_pcm_scan", "k_env_windows3", "k_freq_frames", "k_amp_finish",
+                                                  "k_env_tail") if k in kernels and "hbm_bytes" in kernels[k]]
+        if step and tj.get("algorithmic_bytes_per_launch"):
+            out["whole_step_traffic_ratio"] = sum(step) / tj["algorithmic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError, TypeError) as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and hand their stdout /
+    stderr through; rank 0's JSON line is the only stdout line.  Returns the launcher's exit code."""
+    if not args.plumbing_only:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py --gpus {args.gpus}: this box exposes {have} HIP device(s); the N-GPU run needs "
+                  f"{args.gpus} (one rank per GPU).  Nothing was launched.", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    cmd += [a for a in argv if a != "--launch"]
+    # stdout carries the JSON line and nothing else: whatever a rank or a library prints there
+    # besides it (gloo announces its connections on stdout) goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for out in proc.stdout:
+        dst = sys.stdout if out.lstrip().startswith("{") else sys.stderr
+        dst.write(out)
+        dst.flush()
+    return proc.wait()
+
+
+def plumbing_only(args):
+    """No GPU: the launch / process-group / sharding / all-gather path of an N-rank run with a
+    deterministic stand-in vector per global song index instead of the analysis (which exists on
+    the GPU only).  gloo backend; rank 0 prints one JSON line shaped like the real one."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bliss_amd.dist import gather_force_vectors, shard_range
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" in os.environ:
+        dist.init_process_group("gloo")
+    songs = args.songs_per_gpu if args.songs_per_gpu > 0 else 8
+    total = songs * world
+    first, count = shard_range(total, rank, world)
+    assert count == songs
+
+    def vec(i):
+        return (np.random.default_rng(1000 + i).standard_normal(4) * 10).astype(np.float32)
+
+    mine = torch.from_numpy(np.stack([vec(i) for i in range(first, first + count)]))
+    gathers = 0
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        allv = gather_force_vectors(mine, [songs] * world)
+        gathers += 1
+    if dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ok = bool(np.array_equal(allv.numpy(), np.stack([vec(i) for i in range(total)])))
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing-only (no analysis, stand-in vectors)", "value": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / max(args.steps + args.warmup, 1),
+                          "config": {"workload": f"{songs} stand-in vectors per rank, {total} total",
+                                     "parallelism": f"shard{world}"},
+                          "memory": {"free_bytes_before_alloc": int(free_b), "total_bytes": int(total_b),
+                       "free_bytes_after_alloc": int(mem_after_alloc[0]),
+                       "row_block_bytes": 4 * songs * cols, "emulated_world": args.emulate_world or None},
+            "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
+                                         "all_gather_calls": gathers if dist.is_initialized() else 0,
+                                         "bytes_per_rank": 16 * songs},
+                          "results_ok": ok}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,9 +305,23 @@ def main():
                     help="0 = configs[2] shard (8192) if it fits in HBM, else the largest count that does")
     ap.add_argument("--seconds", type=int, default=SONG_SECONDS, help="song length (default 180)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", type=int, default=4,
+    ap.add_argument("--verify", type=int, default=32,
                     help="songs of the resident batch re-analysed by the CPU oracle after the timed region")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: size the gather buffer and this rank's row block as for a job of W ranks "
+                         "(all_vecs = W x songs vectors, rows = songs x W*songs floats; the other ranks' vectors "
+                         "are copies of this rank's) — checks that the configs[2] shard still fits at W = 8")
+    ap.add_argument("--launch", action="store_true",
+                    help="start the ranks through the self-launcher even for --gpus 1 (RCCL group of one)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU: launch, gloo process group, sharding and all-gather on stand-in vectors")
     args = ap.parse_args()
+
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and (args.gpus > 1 or args.launch):
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if args.plumbing_only:
+        raise SystemExit(plumbing_only(args))
 
     import numpy as np
     import torch
@@ -190,12 +331,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: pass "
+                         f"--nproc-per-node {args.gpus}, or run plain `python bench.py --gpus {args.gpus}` "
+                         "(it launches its own ranks)")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but this box exposes "
+                         f"{torch.cuda.device_count()} HIP device(s) (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-    if world > 1 or under_launcher:  # torchrun: RCCL group even at world size 1
+    if world > 1 or (under_launcher and "MASTER_ADDR" in os.environ):  # torchrun: RCCL group even at world size 1
         dist.init_process_group("nccl", device_id=dev)
 
     import bliss_amd
@@ -210,7 +355,8 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     want = args.songs_per_gpu if args.songs_per_gpu > 0 else 8192
     margin = 8 << 30
-    fit = int((free_b - margin) // (song_bytes + scratch_per_song + 16 + 4 * want * world))
+    fit_world = max(world, args.emulate_world)   # ranks the gather buffer and the row block are sized for
+    fit = int((free_b - margin) // (song_bytes + scratch_per_song + 16 + 4 * want * fit_world))
     songs = want
     capped = False
     if songs > fit:
@@ -224,13 +370,15 @@ def main():
     total_songs = songs * world
     my_first, my_count = shard_range(total_songs, rank, world)
     assert my_count == songs
+    cols = songs * fit_world                      # columns of this rank's row block
 
     corpus = bliss_amd.DeviceCorpus([song_samples] * songs, 2, args.seconds, device=f"cuda:{local_rank}")
     corpus.synth(seed_base=my_first, sample_rate=SAMPLE_RATE)
     torch.cuda.synchronize(dev)
 
-    all_vecs = torch.empty((total_songs, 4), dtype=torch.float32, device=dev)
-    rows = torch.empty((songs, total_songs), dtype=torch.float32, device=dev)
+    all_vecs = torch.empty((cols, 4), dtype=torch.float32, device=dev)
+    rows = torch.empty((songs, cols), dtype=torch.float32, device=dev)
+    mem_after_alloc = torch.cuda.mem_get_info(dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     n_gathers = [0]
@@ -238,9 +386,13 @@ def main():
     def step():
         corpus.analyze()
         mine = corpus.force_vectors()
-        all_vecs.copy_(gather_force_vectors(mine, [songs] * world))   # RCCL all-gather, 16 B/song
+        gathered = gather_force_vectors(mine, [songs] * world)        # RCCL all-gather, 16 B/song
         n_gathers[0] += 1
-        rc = lib.bl_amd_distance_matrix_device(C.c_void_p(all_vecs.data_ptr()), total_songs, my_first,
+        if cols == total_songs:
+            all_vecs.copy_(gathered)
+        else:  # --emulate-world: the absent ranks' blocks are copies of the gathered ones
+            all_vecs.view(cols // total_songs, total_songs, 4).copy_(gathered.unsqueeze(0).expand(cols // total_songs, -1, -1))
+        rc = lib.bl_amd_distance_matrix_device(C.c_void_p(all_vecs.data_ptr()), cols, my_first,
                                                songs, C.c_void_p(rows.data_ptr()), stream)
         assert rc == 0
 
@@ -296,36 +448,45 @@ def main():
         dom = kern["env_windows"]
         launch_bytes = alg_bytes_song * songs     # one env_windows launch covers this rank's batch
         roof = None
+        fir_mode = int(lib.bl_amd_fir_mode())
         if dom["ms_avg"]:
-            ach = launch_bytes / (dom["ms_avg"] * 1e-3) / 1e9
-            # faithful-arithmetic count of the kernel: ~75 f64 VALU instructions per sample
-            # (normalise 4, FIR 26, FFT+split 33, f32-ordered sum 3, log 0.1)
-            f64_rate = 75.0 * song_samples * songs / (dom["ms_avg"] * 1e-3) / 1e12
-            # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE from the committed separate-pass PMC
-            # profile (profiles/*_hbm_traffic.json, corrected as MI355X_MICROARCH.md prescribes),
-            # scaled from its per-song figure to this launch's song count; None if absent
-            traffic = None
-            valu_busy = lds_busy = None   # SQ counters of the same committed profile, if collected
-            try:
-                import glob
-                tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
-                tk = tj["kernels"].get("k_env_windows3") or tj["kernels"]["k_env_windows2"]
-                traffic = tk["hbm_bytes_per_song"] * songs * (song_samples / 15876000.0)
-                valu_busy, lds_busy = tk.get("valu_busy_frac"), tk.get("lds_busy_frac")
-            except Exception:
-                pass
+            t_launch = dom["ms_avg"] * 1e-3
+            ach = launch_bytes / t_launch / 1e9
+            windows = songs * max(2 * (song_samples // 512) - 2, 0)   # ref tempo_atk_sort.c:63-67,120
+            prof = _committed_profile(songs, song_samples)
+            # secondary ceiling, measured: VALU wave-instructions per window from the committed SQ
+            # counters of this kernel (SQ_INSTS_VALU / windows) x the windows of this launch / its
+            # HIP-event time, against the f64 issue rate the chip sustains (tools/ubench_rate.hip)
+            valu = None
+            if prof.get("valu_instr_per_window"):
+                rate = prof["valu_instr_per_window"] * windows / t_launch / 1e12
+                valu = {"achieved_Twaveinstr_per_s": rate, "peak_Twaveinstr_per_s": F64_ISSUE_TWAVEINSTR_S,
+                        "frac": rate / F64_ISSUE_TWAVEINSTR_S,
+                        "valu_instr_per_window_profiled": prof["valu_instr_per_window"],
+                        "valu_busy_frac_profiled": prof.get("valu_busy_frac"),
+                        "lds_busy_frac_profiled": prof.get("lds_busy_frac"),
+                        "source": "SQ_INSTS_VALU of the committed profile (not this run)"}
+            floor_instr = F64_FLOOR_INSTR_PER_WINDOW[fir_mode]
+            floor_s = windows * floor_instr / (F64_ISSUE_TWAVEINSTR_S * 1e12)
             roof = {"bound": "hbm", "kernel": "k_env_windows3", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
-                                      "profiles/*_hbm_traffic.json, scaled per song",
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": prof.get("traffic"), "traffic_error": prof.get("error"),
+                    "traffic_source": {"what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 "
+                                               "corrections of MI355X_MICROARCH.md; per-song figure of the "
+                                               "committed profile scaled to this launch (not collected in this run)",
+                                       "file": prof.get("file"), "git_head_of_profile": prof.get("git_head"),
+                                       "profiled_fir_mode": prof.get("fir_mode")},
                     "frac_of_measured_copy_peak": ach / HBM_ACHIEVABLE_GBS,
                     "ms_avg_launch": dom["ms_avg"], "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": launch_bytes,
-                    "secondary_f64_valu": {"achieved_Tinstr_per_s": f64_rate,
-                                           "peak_Tinstr_per_s": FP64_VALU_PEAK_TFLOPS / 2,
-                                           "frac": f64_rate / (FP64_VALU_PEAK_TFLOPS / 2),
-                                           "valu_busy_frac_profiled": valu_busy,
-                                           "lds_busy_frac_profiled": lds_busy}}
+                    "fir_mode": fir_mode,
+                    "frac_of_f64_floor": floor_s / t_launch,
+                    "f64_floor": {"wave_instr_per_window": floor_instr,
+                                  "issue_rate_Twaveinstr_per_s": F64_ISSUE_TWAVEINSTR_S,
+                                  "what": "static: the f64 operations the arithmetic of this FIR mode needs per "
+                                          "window (DESIGN.md section 4.1) at the measured f64 issue rate"},
+                    "secondary_f64_valu": valu,
+                    "whole_step_traffic_ratio": prof.get("whole_step_traffic_ratio")}
         whole_path_gbs = value / world * alg_bytes_song / 1e9
 
         # BASELINE config 4: standalone 10 000 x 10 000 bl_distance matrix on one GPU

@@ -54,6 +54,11 @@ class SongResult(C.Structure):  # include/bliss_amd.h bl_amd_song_result
                 ("atk_sum", C.c_double)]
 
 
+class Shard(C.Structure):  # include/bliss_amd.h bl_amd_shard
+    _fields_ = [("device", C.c_int32), ("n_songs", C.c_int32), ("d_pcm", C.c_void_p),
+                ("h_desc", C.POINTER(SongDesc)), ("d_results", C.c_void_p), ("d_rows", C.c_void_p)]
+
+
 # every symbol include/*.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 SYMBOLS = {
@@ -100,6 +105,7 @@ SYMBOLS = {
     "bl_amd_analyze_corpus_multi": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32), _P(C.c_uint64),
                                               C.c_int, _P(C.c_int), C.c_int, C.c_int, _P(SongResult),
                                               _P(C.c_float)]),
+    "bl_amd_analyze_corpus_multi_device": (C.c_int, [_P(Shard), C.c_int, C.c_int, _P(SongResult), _P(C.c_float)]),
     "bl_amd_decode_allow_native_rate": (None, [C.c_int]),
     "bl_amd_flac_verify": (C.c_int, [C.c_char_p, _P(C.c_uint8), _P(C.c_uint8)]),
     "bl_amd_analyze_batch_host": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
@@ -111,6 +117,8 @@ SYMBOLS = {
     "bl_amd_playlist_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bl_amd_playlist_host": (C.c_int, [_P(ForceVector), C.c_int, C.c_int, _P(C.c_int32), _P(C.c_float)]),
     "bl_amd_synth_pcm_device": (C.c_int, [C.c_void_p, _P(SongDesc), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "bl_amd_set_fir_mode": (C.c_int, [C.c_int]),
+    "bl_amd_fir_mode": (C.c_int, []),
     "bl_amd_profile": (None, [C.c_int]),
     "bl_amd_profile_reset": (None, []),
     "bl_amd_profile_ms": (C.c_double, [C.c_char_p, _P(C.c_int)]),

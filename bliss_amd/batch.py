@@ -195,6 +195,36 @@ def analyze_corpus_multi(pcm_list, channels, durations, devices, gather="rccl", 
     return results_to_numpy(bytes(out)), mat
 
 
+def analyze_corpus_multi_device(corpora, gather="rccl", matrix=True, keep_rows=False):
+    """Resident corpora, one DeviceCorpus per rank (each on its rank's device; several on one
+    device with gather="peer"): analyse every shard where it lies, all-gather the force vectors,
+    row blocks of the bl_distance matrix (bl_amd_analyze_corpus_multi_device).  Returns
+    (results in shard-major order, N x N matrix or None, list of per-shard row-block CUDA tensors
+    or None)."""
+    lib = _lib.load()
+    torch = corpora[0].torch
+    n = sum(c.n_songs for c in corpora)
+    shards = (_lib.Shard * len(corpora))()
+    rows = []
+    for r, c in enumerate(corpora):
+        c.torch.cuda.synchronize(c.device)   # the arena was filled on torch's stream
+        shards[r].device = c.device.index or 0
+        shards[r].n_songs = c.n_songs
+        shards[r].d_pcm = c.pcm.data_ptr()
+        shards[r].h_desc = C.cast(c.desc, C.POINTER(_lib.SongDesc))
+        shards[r].d_results = c.results.data_ptr()
+        if keep_rows:
+            rows.append(torch.empty((c.n_songs, n), dtype=torch.float32, device=c.device))
+            shards[r].d_rows = rows[-1].data_ptr()
+    out = (_lib.SongResult * n)()
+    mat = np.empty((n, n), dtype=np.float32) if matrix else None
+    mp = mat.ctypes.data_as(C.POINTER(C.c_float)) if matrix else None
+    flags = {"rccl": 0, "peer": 1}[gather]
+    _check(lib.bl_amd_analyze_corpus_multi_device(shards, len(corpora), flags, out, mp),
+           "bl_amd_analyze_corpus_multi_device")
+    return results_to_numpy(bytes(out)), mat, (rows if keep_rows else None)
+
+
 def resample_host(pcm, channels, in_rate):
     """Interleaved int16 / int32 (left-justified) numpy PCM at in_rate Hz -> interleaved stereo int16
     at 22 050 Hz, the conversion bl_audio_decode applies (include/bliss_amd.h)."""

@@ -192,14 +192,17 @@ void bl_rectangular_filter(double *sample_array_out, double *sample_array_in, in
   const double *const end = sample_array_in + nSamples;
   double run = 0;
   for (const double *p = lag; p < lead; ++p) run += *p;
-  double *centre = sample_array_out + (int)round(smooth_width / 2.) - 1;
+  const int half = (int)round(smooth_width / 2.);
+  double *centre = sample_array_out + half - 1;
   while (lead < end) { /* slide: drop the oldest input, then take the next one */
     *centre++ = run;
     run -= *lag++;
     run += *lead++;
   }
-  /* here centre == &out[n - half] and lag == &in[n - width]: the last window is added to
-   * whatever that cell held */
-  for (; lag < end; ++lag) *centre += *lag;
+  /* lag == &in[n - width]: the last window is added to whatever out[n - half] held.  For an odd
+   * width that is the cell `centre` has reached; for an even one it is the cell after it (the
+   * reference names the index, ref :32-33), so the index is named here too. */
+  double *const last = sample_array_out + (nSamples - half);
+  for (; lag < end; ++lag) *last += *lag;
   for (int k = 0; k < nSamples; ++k) sample_array_out[k] /= smooth_width;
 }

@@ -33,6 +33,7 @@
  */
 #include <ctype.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,16 +45,19 @@
 
 #define BL_DECODE_RATE 22050 /* ref src/decode.c:7 SAMPLE_RATE */
 
-static int g_allow_native_rate = -1; /* -1: not set, look at the environment */
+/* -1: not set by the caller, the environment decides.  Read and written with relaxed atomics: the
+ * setter may run on one thread while decodes run on others, and either value is a valid answer. */
+static int g_allow_native_rate = -1;
 
-void bl_amd_decode_allow_native_rate(int allow) { g_allow_native_rate = allow != 0; }
+void bl_amd_decode_allow_native_rate(int allow) {
+  __atomic_store_n(&g_allow_native_rate, allow != 0, __ATOMIC_RELAXED);
+}
 
 static int native_rate_allowed(void) {
-  if (g_allow_native_rate < 0) {
-    const char *e = getenv("BL_AMD_ALLOW_NATIVE_RATE");
-    g_allow_native_rate = e && *e && strcmp(e, "0") != 0;
-  }
-  return g_allow_native_rate;
+  const int v = __atomic_load_n(&g_allow_native_rate, __ATOMIC_RELAXED);
+  if (v >= 0) return v;
+  const char *e = getenv("BL_AMD_ALLOW_NATIVE_RATE"); /* not cached: getenv is cheap next to a decode */
+  return e && *e && strcmp(e, "0") != 0;
 }
 
 /* a sample of `bps` significant bits as the s16 the analyzers read: left-justify in 32 bits,
@@ -275,21 +279,16 @@ static void md5_block(uint32_t h[4], const uint8_t *p) {
                                   5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20,
                                   4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
                                   6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
-  static uint32_t K[64];
-  static int have_k = 0;
-  if (!have_k) { /* K[i] = floor(2^32 * |sin(i + 1)|), as integers from a table-free recurrence */
-    static const uint32_t k0[64] = {
-        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
-        0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
-        0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
-        0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
-        0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
-        0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
-        0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
-        0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
-    memcpy(K, k0, sizeof K);
-    have_k = 1;
-  }
+  /* K[i] = floor(2^32 * |sin(i + 1)|) */
+  static const uint32_t K[64] = {
+      0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+      0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+      0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+      0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+      0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+      0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+      0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+      0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
   uint32_t w[16];
   for (int i = 0; i < 16; ++i) w[i] = le32(p + 4 * i);
   uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
@@ -480,19 +479,22 @@ static uint8_t flac_crc8(const uint8_t *p, size_t n) {
   return c;
 }
 
-static uint16_t flac_crc16(const uint8_t *p, size_t n) {
-  static uint16_t tab[256];
-  static int ready = 0;
-  if (!ready) {
-    for (int v = 0; v < 256; ++v) {
-      uint16_t c = (uint16_t)(v << 8);
-      for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1);
-      tab[v] = c;
-    }
-    ready = 1;
+/* bl_audio_decode is the call callers run on many threads at once: the table is built exactly
+ * once, with the stores ordered before any reader (pthread_once) */
+static uint16_t g_crc16_tab[256];
+static pthread_once_t g_crc16_once = PTHREAD_ONCE_INIT;
+static void flac_crc16_init(void) {
+  for (int v = 0; v < 256; ++v) {
+    uint16_t c = (uint16_t)(v << 8);
+    for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1);
+    g_crc16_tab[v] = c;
   }
+}
+
+static uint16_t flac_crc16(const uint8_t *p, size_t n) {
+  pthread_once(&g_crc16_once, flac_crc16_init);
   uint16_t c = 0;
-  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ tab[(c >> 8) ^ p[i]]);
+  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ g_crc16_tab[(c >> 8) ^ p[i]]);
   return c;
 }
 
@@ -581,6 +583,14 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
     if (coded != (variable_blocks ? frames_done : frames_seen)) { rc = BL_UNEXPECTED; break; }
     uint32_t nch = chan < 8 ? chan + 1 : 2;
     if (nch != fi.channels) { rc = BL_UNEXPECTED; break; }
+    if (bps == 32 && chan >= 8) {
+      /* a side channel of a 32-bit stream has 33 bits: beyond the 32-bit reader and sample
+       * buffers of this decoder.  Refused, not decoded to wrong samples (the frame CRCs would
+       * still pass). */
+      fprintf(stderr, "bliss_amd: 32-bit FLAC with inter-channel decorrelation is not supported\n");
+      rc = BL_UNEXPECTED;
+      break;
+    }
     int bad = 0;
     for (uint32_t c = 0; c < nch && !bad; ++c) {
       uint32_t cb = bps;

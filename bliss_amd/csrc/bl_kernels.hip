@@ -28,6 +28,7 @@
  *   k_synth        integer synthetic PCM (benchmark corpus)
  */
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <algorithm>
 #include <math.h>
 #include <stdio.h>
@@ -207,6 +208,9 @@ __device__ __forceinline__ void prep_finish(bl_dstats &s, int n) {
   const double v2 = 2.0 * s.vprime;
   s.rcp = 1.0 / v2;
   s.rcp_lo = __builtin_fma(-s.rcp, v2, 1.0) / v2;
+  const double taps[9] = {BL_C0, BL_C1, BL_C2, BL_C3, BL_C4, BL_C5, BL_C6, BL_C7, BL_C8};
+#pragma unroll
+  for (int m = 0; m < 9; ++m) s.firc[m] = __builtin_fma(taps[m], s.rcp, taps[m] * s.rcp_lo);
   (void)n;
 }
 
@@ -668,6 +672,48 @@ __device__ __forceinline__ double bl_norm(int k, double rcp, double rcp_lo) {
     y_;                                                             \
   })
 
+/* The same sum with each product folded into the running sum by an fma: eight roundings fewer per
+ * output and eight instructions fewer (17 instead of 25).  NOT the reference's arithmetic: an
+ * output differs by a few 1e-16 of its largest partial sum, which is the class of difference the
+ * DFT behind it already has (ours, not FFTW's) and which the results see only through the f32
+ * roundings of the ordered sum.  Selected by BL_AMD_FIR_FUSED=1; DESIGN.md §4.1 has the measured
+ * flip rates that decide whether it is used. */
+#define BL_FIR_FUSED(X)                                             \
+  ({                                                                \
+    double y_ = BL_C7 * (X(7) + X(9));                              \
+    y_ = __builtin_fma(BL_C6, X(6) + X(10), y_);                    \
+    y_ = __builtin_fma(BL_C5, X(5) + X(11), y_);                    \
+    y_ = __builtin_fma(BL_C4, X(4) + X(12), y_);                    \
+    y_ = __builtin_fma(BL_C3, X(3) + X(13), y_);                    \
+    y_ = __builtin_fma(BL_C2, X(2) + X(14), y_);                    \
+    y_ = __builtin_fma(BL_C1, X(1) + X(15), y_);                    \
+    y_ = __builtin_fma(X(8), BL_C8, y_);                            \
+    y_ = __builtin_fma(BL_C0, X(0) + X(16), y_);                    \
+    y_;                                                             \
+  })
+/* Mode 2: the normalisation folded into the taps.  k = s - mean is an exact integer and so is every
+ * pair sum; c'_m = RN(c_m / (2 vprime)) (k_song_prep) carries the division.  One rounding per tap
+ * (the product inside the fma) where the reference has three (quotient, pair sum, product): the
+ * output differs from the reference's by a few 1e-16 of its largest partial sum, as in mode 1, and
+ * the 66 f64 instructions per round that normalise the samples are gone.  FC(m) names tap m. */
+#define BL_FIR_FOLD(X, FC)                                          \
+  ({                                                                \
+    double y_ = FC(7) * (X(7) + X(9));                              \
+    y_ = __builtin_fma(FC(6), X(6) + X(10), y_);                    \
+    y_ = __builtin_fma(FC(5), X(5) + X(11), y_);                    \
+    y_ = __builtin_fma(FC(4), X(4) + X(12), y_);                    \
+    y_ = __builtin_fma(FC(3), X(3) + X(13), y_);                    \
+    y_ = __builtin_fma(FC(2), X(2) + X(14), y_);                    \
+    y_ = __builtin_fma(FC(1), X(1) + X(15), y_);                    \
+    y_ = __builtin_fma(X(8), FC(8), y_);                            \
+    y_ = __builtin_fma(FC(0), X(0) + X(16), y_);                    \
+    y_;                                                             \
+  })
+#ifndef BL_FIR_FUSED_DEFAULT
+#define BL_FIR_FUSED_DEFAULT 2
+#endif
+#define BL_FIR_SEL(MODE, X, FC) ((MODE) == 2 ? BL_FIR_FOLD(X, FC) : (MODE) == 1 ? BL_FIR_FUSED(X) : BL_FIR(X))
+
 /* ------------------------------------------------------------------------- */
 /* k_env_windows2: normalise + FIR + DFT + ordered sum, wave-autonomous      */
 /*
@@ -1014,6 +1060,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 #define EV3_FLAG_OFF (EV3_TW_OFF + 2 * 256 * 16)
 #define EV3_LDS_BYTES (EV3_FLAG_OFF + 64)
 
+template <int FIR_MODE>
 __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
     const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
     const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc) {
@@ -1092,6 +1139,9 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
   double *buf = reinterpret_cast<double *>(smem) + wave * EV3_SLOTS;
   const int mean = st.mean;
   const double rcp = st.rcp, rcp_lo = st.rcp_lo;
+#define FC(m) st.firc[m]
+  /* mode 2 filters the integers k = s - mean themselves (the taps carry the division) */
+  auto nrm = [&](int k) -> double { return FIR_MODE == 2 ? (double)k : bl_norm(k, rcp, rcp_lo); };
   const int r0 = run_begin(u0 + wave), r1 = run_begin(u0 + wave + 1);
   constexpr int EV3_W1_REGS = 13; /* pass-1 twiddles 1..12 in registers, 13..15 from LDS */
   c2d w1r[EV3_W1_REGS];
@@ -1114,15 +1164,15 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-        r[4 * u + 2 * k] = ok ? bl_norm(lo - mean, rcp, rcp_lo) : 0.0;
-        r[4 * u + 2 * k + 1] = ok ? bl_norm(hi - mean, rcp, rcp_lo) : 0.0;
+        r[4 * u + 2 * k] = ok ? nrm(lo - mean) : 0.0;
+        r[4 * u + 2 * k + 1] = ok ? nrm(hi - mean) : 0.0;
       }
     }
     double *dst = buf + base5 * EV3_BLK + (ln >> 2) * 18 + 4 * (ln & 3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #define XW(m) r[i + 16 - (m)]
-      dst[i] = BL_FIR(XW);
+      dst[i] = BL_FIR_SEL(FIR_MODE, XW, FC);
 #undef XW
     }
   }
@@ -1160,17 +1210,17 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-          r[8 * u + 2 * k] = bl_norm(lo - mean, rcp, rcp_lo);
-          r[8 * u + 2 * k + 1] = bl_norm(hi - mean, rcp, rcp_lo);
+          r[8 * u + 2 * k] = nrm(lo - mean);
+          r[8 * u + 2 * k + 1] = nrm(hi - mean);
         }
       }
-      const double xh = bl_norm((int)preh - mean, rcp, rcp_lo);
+      const double xh = nrm((int)preh - mean);
       fetch(rho + 1); /* next round's samples */
       /* 2. FIR (ref :123-138): outputs 16 ln .. 16 ln + 15 of the round's new samples */
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
 #define XR(m) r[i + 16 - (m)]
-        yv[i] = BL_FIR(XR);
+        yv[i] = BL_FIR_SEL(FIR_MODE, XR, FC);
 #undef XR
       }
       /* zero-state heads of the four windows, as in k_env_windows2 */
@@ -1183,7 +1233,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
       hx[13] = bl_dpp_f64<0x11D>(xh); hx[14] = bl_dpp_f64<0x11E>(xh); hx[15] = bl_dpp_f64<0x11F>(xh);
       hx[16] = 0.0;
 #define XH(m) hx[m]
-      yh = BL_FIR(XH);
+      yh = BL_FIR_SEL(FIR_MODE, XH, FC);
 #undef XH
     }
     /* ring positions: window g reads block g (first half) and block g + 1 (second half); the
@@ -1264,6 +1314,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
     base5 = base5 == 0 ? 4 : base5 - 1; /* (4 (rho + 1)) mod 5 */
   }
 }
+#undef FC
 
 /* ------------------------------------------------------------------------- */
 /* k_env_tail: one lane per song, three waves per 64 songs                    */
@@ -1637,7 +1688,11 @@ int blk_configure_device(void) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3),
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
@@ -1658,6 +1713,32 @@ struct Mark {
     if (fn) fn(user, k, s, 0);
   }
 };
+
+} // namespace
+
+/* Which form of the 17-tap FIR k_env_windows3 runs:
+ *   0  the reference's unfused order (BL_FIR) — bit-identical window energies;
+ *   1  each product folded into the sum by an fma (BL_FIR_FUSED);
+ *   2  as 1, with the normalisation folded into the taps (BL_FIR_FOLD) — the default.
+ * bl_amd_set_fir_mode() wins over the environment variable BL_AMD_FIR_FUSED, which wins over the
+ * compiled default.  Read on every launch, so one process can run all of them (the A/B tools do). */
+static std::atomic<int> g_fir_mode{-1};
+int blk_fir_mode() {
+  int m = g_fir_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char *e = getenv("BL_AMD_FIR_FUSED");
+    m = e && *e ? atoi(e) : BL_FIR_FUSED_DEFAULT;
+  }
+  return m < 0 || m > 2 ? BL_FIR_FUSED_DEFAULT : m;
+}
+extern "C" int bl_amd_fir_mode(void) { return blk_fir_mode(); }
+extern "C" int bl_amd_set_fir_mode(int mode) {
+  if (mode < -1 || mode > 2) return BL_UNEXPECTED;
+  g_fir_mode.store(mode, std::memory_order_relaxed);
+  return BL_OK;
+}
+
+namespace {
 
 int grid_x_for(long long units_max, int n_songs, int blocks_per_cu, int n_cu) {
   /* enough blocks to fill the chip several times over, never more than the
@@ -1708,8 +1789,14 @@ int blk_analyze(const blk_analyze_args &a) {
         hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
                            EV2_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc,
                            a.env_dbg);
+      else if (!old_env && blk_fir_mode() == 2)
+        hipLaunchKernelGGL(k_env_windows3<2>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
+      else if (!old_env && blk_fir_mode() == 1)
+        hipLaunchKernelGGL(k_env_windows3<1>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
       else if (!old_env)
-        hipLaunchKernelGGL(k_env_windows3, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+        hipLaunchKernelGGL(k_env_windows3<0>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
                            EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
       else
         hipLaunchKernelGGL(k_env_windows2<false>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),

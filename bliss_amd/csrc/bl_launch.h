@@ -41,6 +41,8 @@ struct bl_dstats {
   int wrap_pass; /* 1: variance must come from k_variance_wrap */
   int status;
   long long wrap_acc; /* accumulator of k_variance_wrap */
+  double firc[9];     /* RN(c_m / (2 vprime)), m = 0..8: the FIR taps with the normalisation folded in
+                       * (BL_AMD_FIR_FUSED=2 only) */
 };
 
 typedef bl_c2<double> c2d;

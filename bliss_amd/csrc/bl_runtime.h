@@ -72,6 +72,9 @@ struct bl_amd_ctx {
   bl_buf arena22[2]; /* converted (22 050 Hz) songs of a wave whose input is at another rate */
   hipStream_t streams[2] = {nullptr, nullptr};
   std::vector<void *> registered[2]; /* host ranges pinned in place for wave k */
+  /* multi-device corpus path (bl_multi.hip): this rank's vectors, the gathered blocks, the
+   * vectors in output order, the order table and the row block — grown on demand, kept */
+  bl_buf mx_my, mx_gath, mx_all, mx_order, mx_rows;
   /* device rate converter: the plan of the last (input rate, sample kind) stays uploaded */
   bl_buf rs_songs, rs_bank;
   int rs_rate = 0, rs_kind = -1, rs_bank_lds = 0;

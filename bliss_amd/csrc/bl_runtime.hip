@@ -127,7 +127,7 @@ void ctx_release(bl_amd_ctx *c) {
   prof_collect(c);
   bl_buf *bufs[] = {&c->songs,   &c->stats,   &c->hist, &c->spectrum, &c->energies, &c->lc,
                     &c->results, &c->misc,    &c->arena[0], &c->arena[1], &c->arena22[0], &c->arena22[1],
-                    &c->rs_songs, &c->rs_bank};
+                    &c->rs_songs, &c->rs_bank, &c->mx_my, &c->mx_gath, &c->mx_all, &c->mx_order, &c->mx_rows};
   for (bl_buf *b : bufs) release_buf(*b);
   for (int k = 0; k < 2; ++k) {
     unregister_wave(c, k);
@@ -452,12 +452,11 @@ int blr_resample_device(bl_amd_ctx *c, const void *d_in, int in_is_s32, const bl
 #endif
 
 static int stage_threads(void) {
-  static int n = 0;
-  if (!n) {
+  static const int n = [] { /* initialised once, thread-safe (C++11 function-local static) */
     const char *e = getenv("BL_AMD_STAGE_THREADS");
-    n = e ? atoi(e) : BL_STAGE_THREADS;
-    n = n < 1 ? 1 : (n > 64 ? 64 : n);
-  }
+    const int v = e ? atoi(e) : BL_STAGE_THREADS;
+    return v < 1 ? 1 : (v > 64 ? 64 : v);
+  }();
   return n;
 }
 
@@ -520,7 +519,12 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
    * kernels: the device arena is reused in stream order.  Waiting for the kernels put the
    * ~20 ms latency of the serial envelope tail between two transfers (44 instead of 55 GB/s). */
   hipEvent_t done[2] = {nullptr, nullptr};
-  for (int k = 0; k < 2; ++k) BL_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+  for (int k = 0; k < 2 && rc == BL_OK; ++k) /* every exit below goes through the cleanup loop */
+    if (hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess) {
+      fprintf(stderr, "bliss_amd: hipEventCreateWithFlags failed (%s:%d)\n", __FILE__, __LINE__);
+      done[k] = nullptr;
+      rc = BL_UNEXPECTED;
+    }
   bool used[2] = {false, false};
   while (begin < n_songs && rc == BL_OK) {
     const int k = wave & 1;
@@ -636,7 +640,7 @@ int blr_analyze_host(bl_amd_ctx *c, const void *const *h_pcm, int pcm_is_s32, co
   for (int k = 0; k < 2; ++k) {
     if (c->streams[k] && hipStreamSynchronize(c->streams[k]) != hipSuccess) rc = BL_UNEXPECTED;
     unregister_wave(c, k);
-    (void)hipEventDestroy(done[k]);
+    if (done[k]) (void)hipEventDestroy(done[k]);
   }
   if (rc == BL_OK && h_results &&
       hipMemcpy(h_results, d_res, sizeof(bl_amd_song_result) * (size_t)n_songs, hipMemcpyDeviceToHost) != hipSuccess)

@@ -168,6 +168,28 @@ int bl_amd_analyze_corpus_multi(const int16_t *const *h_pcm, const int32_t *n_sa
                                 const int *devices, int n_devices, int flags,
                                 bl_amd_song_result *h_results, float *h_matrix);
 
+/* The same for a corpus that is already RESIDENT in the GPUs' memory (configs[2] proper: 8 192
+ * three-minute songs are 260 GB per GPU — they are decoded, converted or generated into each
+ * GPU's HBM in waves, never held in host memory at once).  One bl_amd_shard per rank: the arena
+ * on that rank's device and its songs; the corpus order is shard-major (all songs of shard 0,
+ * then shard 1, ...).  Every rank analyses its arena where it lies (a host thread and a context
+ * per rank), the force vectors are all-gathered as above, and rank r computes the rows of its
+ * own songs against all N.  d_results (optional, on the shard's device): the shard's records;
+ * d_rows (optional, on the shard's device): n_songs x N floats, the shard's row block, which
+ * stays in HBM.  h_results (optional): N records in corpus order.  h_matrix (optional): N x N
+ * floats.  Blocking.  The reference's corpus loop this replaces: python/examples/
+ * make_m3u_playlist.py:51-72 (analyse every file, then distances from the vectors). */
+typedef struct bl_amd_shard {
+  int32_t device;                  /* HIP device the arena lives on */
+  int32_t n_songs;
+  const int16_t *d_pcm;            /* arena base, on `device` */
+  const bl_amd_song_desc *h_desc;  /* host array of n_songs descriptors */
+  bl_amd_song_result *d_results;   /* NULL, or n_songs records on `device` */
+  float *d_rows;                   /* NULL, or n_songs * N floats on `device` */
+} bl_amd_shard;
+int bl_amd_analyze_corpus_multi_device(const bl_amd_shard *shards, int n_shards, int flags,
+                                       bl_amd_song_result *h_results, float *h_matrix);
+
 /* bl_audio_decode() follows the reference in always presenting 22 050 Hz PCM to the
  * analyzers (ref src/decode.c:7-9,317-346): a file at another rate, or wider than 16 bits at
  * another rate, goes through a restatement of libswresample's default converter and comes out
@@ -205,6 +227,19 @@ int bl_amd_playlist_host(const struct force_vector_s *h_vecs, int n, int seed_in
  * h_desc[i].pcm_offset.  Byte-identical to oracle/orc_synth.c. */
 int bl_amd_synth_pcm_device(int16_t *d_pcm, const bl_amd_song_desc *h_desc, int n_songs,
                             uint32_t seed_base, uint32_t sample_rate, void *stream);
+
+/* Arithmetic of the envelope kernel's 17-tap FIR (ref src/tempo_atk_sort.c:123-138):
+ *   0  the reference's order, every product and sum rounded separately: window energies
+ *      bit-identical to the reference arithmetic;
+ *   1  the same sum with the products folded in by fused multiply-adds;
+ *   2  (default) as 1, and the normalisation of ref :109-114 folded into the taps.
+ * 1 and 2 differ from 0 by a few 1e-16 of an output's largest partial sum — what a different
+ * FFT library behind it already does — and are 9 % / 12 % faster.  Measured on 127 million windows
+ * of 2 048 three-minute songs: 2 f32 window energies move, by one ulp, no integer and no feature
+ * changes; expected `beat` changes per song ~1e-9.  mode -1 = follow the
+ * environment variable BL_AMD_FIR_FUSED, else the default.  Process-wide. */
+int bl_amd_set_fir_mode(int mode);
+int bl_amd_fir_mode(void);
 
 /* Per-kernel device time, measured with hipEvents on the launch stream while
  * profiling is on (bench.py's roofline leg).  name is one of "pcm_scan",

@@ -79,7 +79,7 @@ def test_scalar_helpers_are_the_reference_expressions(lib, oracle):
         assert lib.bl_distance(a, b) == oracle.distance(v[i], v[i + 1])
         assert lib.bl_cosine_similarity(a, b) == oracle.cosine(v[i], v[i + 1])
     dp = C.POINTER(C.c_double)
-    for n, w in ((500, 19), (20, 19), (40, 19), (64, 7)):
+    for n, w in ((500, 19), (20, 19), (40, 19), (64, 7), (40, 4), (64, 8), (33, 2), (19, 19), (8, 8)):  # even widths too
         inp, old = rng.standard_normal(n), rng.standard_normal(n)
         out = old.copy()
         lib.bl_rectangular_filter(out.ctypes.data_as(dp), inp.ctypes.data_as(dp), n, w)

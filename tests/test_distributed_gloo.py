@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -98,3 +99,38 @@ def test_shard_helpers():
     assert abs(loads[0] - loads[1]) <= 40
     for s in shards:
         assert [lengths[i] for i in s] == sorted((lengths[i] for i in s), reverse=True)
+
+
+def test_bench_self_launch_plumbing():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks (torch.distributed.run
+    on 127.0.0.1) and rank 0 prints exactly one JSON line; --plumbing-only runs that path on CPU:
+    gloo group, shard ranges, the all-gather of stand-in vectors — the analysis itself is GPU-only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--plumbing-only", "--songs-per-gpu", "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["results_ok"] is True
+    assert line["collective"] == {"backend": "gloo", "all_gather_calls": 3, "bytes_per_rank": 80}
+    assert line["config"]["parallelism"] == "shard2"
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """Plain `--gpus 2` on a box with fewer devices fails before anything is launched, with a
+    message about the device count (not about WORLD_SIZE)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("box has two devices")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert "HIP device(s)" in r.stderr and "WORLD_SIZE" not in r.stderr

@@ -211,6 +211,49 @@ def test_corpus_multi(gpu_lib, oracle, devices, gather):
     assert none is None
 
 
+@pytest.mark.parametrize("counts,gather", [((5,), "rccl"), ((4, 3), "peer"), ((3, 0, 4), "peer"), ((2, 3, 2), "peer")])
+def test_corpus_multi_device_resident(gpu_lib, oracle, counts, gather):
+    """bl_amd_analyze_corpus_multi_device: the corpus already resident, one arena per rank (here
+    all on device 0, separate contexts and host threads; an empty shard included).  Records and
+    matrix must equal the single-context path bit for bit, the row blocks left in HBM too."""
+    import torch
+    songs = _songs(oracle, 4700, sum(counts))
+    pcms, chans, durs = [p for p, _, _ in songs], [c for _, c, _ in songs], [d for _, _, d in songs]
+    whole = bliss_amd.DeviceCorpus([p.size for p in pcms], chans, durs)
+    for i, p in enumerate(pcms):
+        whole.upload(i, p)
+    whole.analyze()
+    single = whole.fetch()
+    fv = np.stack([single[k] for k in ("tempo", "amplitude", "frequency", "attack")], axis=1)
+    want = bliss_amd.distance_matrix(fv)
+    corpora, first = [], 0
+    for cnt in counts:
+        part = range(first, first + cnt)
+        c = bliss_amd.DeviceCorpus([pcms[i].size for i in part] or [8], [chans[i] for i in part] or [1],
+                                   [durs[i] for i in part] or [1])
+        if cnt == 0:
+            c.n_songs = 0          # an empty shard: the arena exists, nothing to analyse
+        for k, i in enumerate(part):
+            c.upload(k, pcms[i])
+        corpora.append(c)
+        first += cnt
+    for _ in range(2):             # second call: the contexts' exchange buffers are reused
+        res, mat, rows = bliss_amd.analyze_corpus_multi_device(corpora, gather=gather, keep_rows=True)
+        _same(single, res)
+        assert np.array_equal(mat, want) and np.array_equal(mat, oracle.distance_matrix(fv))
+        torch.cuda.synchronize()
+        assert np.array_equal(np.concatenate([r.cpu().numpy() for r in rows], axis=0), want)
+    # the shard's own device records are the same records
+    off = 0
+    for c in corpora:
+        if c.n_songs:
+            _same(single[off:off + c.n_songs], c.fetch()[:c.n_songs])
+        off += c.n_songs
+    res2, none, _ = bliss_amd.analyze_corpus_multi_device(corpora, gather=gather, matrix=False)
+    _same(single, res2)
+    assert none is None
+
+
 def test_scalar_helpers_match_the_kernels(gpu_lib):
     """bl_distance / bl_cosine_similarity of one pair are host arithmetic (bl_api.c): the same
     bits as the all-pairs kernels."""

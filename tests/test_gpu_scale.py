@@ -27,9 +27,24 @@ def _energies(lib, got):
 
 
 def _check_sample(lib, oracle, corpus, got, picks, rate, channels, seconds, seed_base, tag):
+    """`got`: the batch as the default FIR mode analysed it (the library's last batch).  Features and
+    integers are held against the oracle as they are; the window energies of the default mode may
+    sit one f32 ulp off the reference arithmetic in about one window per 10^8 (bl_amd_set_fir_mode),
+    so they are compared with that allowance and then — after a second analysis in mode 0, the
+    reference's own FIR — bit for bit."""
     en, offs = _energies(lib, got)
+    try:
+        assert lib.bl_amd_set_fir_mode(0) == 0
+        corpus.analyze()
+        got0 = corpus.fetch()
+        en0, _ = _energies(lib, got0)
+    finally:
+        lib.bl_amd_set_fir_mode(-1)
+    for k in got.dtype.names:
+        assert np.array_equal(got[k], got0[k]), (tag, "default FIR mode vs mode 0", k)
     n = rate * channels * seconds
     pcm = corpus.pcm
+    moved = 0
     for i in picks:
         o = int(corpus.desc[i].pcm_offset)
         song = pcm[o:o + n].cpu().numpy()
@@ -40,8 +55,12 @@ def _check_sample(lib, oracle, corpus, got, picks, rate, channels, seconds, seed
         full = oracle.analyze(song, channels, seconds)
         check_song(got[i], full, f"{tag}[{i}]")
         nw = int(got[i]["n_windows"])
-        mine = en[offs[i]:offs[i] + nw]
-        assert np.array_equal(mine.view(np.uint32), ref_en[:nw].view(np.uint32)), (tag, i, "window energies")
+        assert np.array_equal(en0[offs[i]:offs[i] + nw].view(np.uint32), ref_en[:nw].view(np.uint32)), \
+            (tag, i, "window energies, mode 0")
+        d = np.abs(en[offs[i]:offs[i] + nw].view(np.int32).astype(np.int64) - ref_en[:nw].view(np.int32).astype(np.int64))
+        assert d.max() <= 1, (tag, i, "window energies, default mode: more than one ulp", int(d.max()))
+        moved += int(np.count_nonzero(d))
+    assert moved <= 2, (tag, "window energies, default mode", moved)
 
 
 def test_configs1_full_count(gpu_lib, oracle):
@@ -89,3 +108,58 @@ def test_bench_under_torchrun_runs_rccl_and_verifies(gpu_lib):
     assert line["n_gpus"] == 1 and line["results_ok"] is True and line["verified_songs"] == 4
     assert line["collective"]["backend"] == "nccl" and line["collective"]["all_gather_calls"] >= 2
     assert line["roofline"]["kernel"] and line["value"] > 0
+
+
+def test_bench_self_launch(gpu_lib):
+    """The driver's own command form, `python bench.py --gpus N ...` with no launcher around it:
+    --launch takes the N = 1 case through the same self-launch path N > 1 uses (ranks started
+    under torch.distributed.run on 127.0.0.1, RCCL process group, one JSON line on stdout)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch", "--steps", "2", "--warmup", "1",
+           "--songs-per-gpu", "16", "--seconds", "20", "--no-cpu-baseline", "--verify", "4"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["results_ok"] is True
+    assert line["collective"]["backend"] == "nccl" and line["collective"]["all_gather_calls"] >= 2
+    assert line["verified_songs"] == 4 and line["roofline"]["frac"] > 0
+    # more ranks than devices: refused before anything is launched, and the message says why
+    import torch
+    if torch.cuda.device_count() == 1:
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r2.returncode == 2 and r2.stdout.strip() == ""
+        assert "1 HIP device(s)" in r2.stderr and "WORLD_SIZE" not in r2.stderr
+
+
+def test_fir_modes_agree(gpu_lib, oracle):
+    """The three forms of the envelope FIR (bl_amd_set_fir_mode): mode 0 is the reference's
+    arithmetic and must give the oracle's window energies bit for bit; modes 1 and 2 may move an
+    energy by one f32 ulp about once per 10^8 windows — here: every integer equal, every float
+    feature equal, at most 2 of the ~2.6 million energies one ulp apart."""
+    n = 44100 * 2 * 30
+    corpus = bliss_amd.DeviceCorpus([n] * 256, 2, 30)
+    corpus.synth(seed_base=52000, sample_rate=44100)
+    try:
+        out = {}
+        for mode in (0, 1, 2):
+            assert gpu_lib.bl_amd_set_fir_mode(mode) == 0 and gpu_lib.bl_amd_fir_mode() == mode
+            corpus.analyze()
+            got = corpus.fetch()
+            en, offs = _energies(gpu_lib, got)
+            out[mode] = (got, en.copy())
+        g0, e0 = out[0]
+        song = corpus.pcm[int(corpus.desc[7].pcm_offset):int(corpus.desc[7].pcm_offset) + n].cpu().numpy()
+        _, ref_en = oracle.envelope(song, 30)
+        nw = int(g0[7]["n_windows"])
+        assert np.array_equal(e0[offs[7]:offs[7] + nw].view(np.uint32), ref_en[:nw].view(np.uint32))
+        for mode in (1, 2):
+            g, e = out[mode]
+            for k in g.dtype.names:
+                assert np.array_equal(g[k], g0[k]), (mode, k)
+            d = np.abs(e.view(np.int32).astype(np.int64) - e0.view(np.int32).astype(np.int64))
+            assert d.max() <= 1 and np.count_nonzero(d) <= 2, (mode, int(d.max()), int(np.count_nonzero(d)))
+    finally:
+        gpu_lib.bl_amd_set_fir_mode(-1)
+    assert gpu_lib.bl_amd_set_fir_mode(3) == bliss_amd.BL_UNEXPECTED

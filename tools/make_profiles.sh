@@ -7,7 +7,7 @@
 #   bench_8192songs.json                the default bench line outside the profiler
 # usage: tools/make_profiles.sh [tag] [songs for the PMC passes]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 PSONGS=${2:-8192}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG

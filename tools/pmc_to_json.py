@@ -12,6 +12,26 @@ SONGS = 256
 ALGO_BYTES_PER_SONG = 15876000 * 2  # 180 s x 44.1 kHz x 2 ch x s16
 
 
+def _read(name):
+    import os
+    try:
+        return open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), name)).read().strip()
+    except OSError:
+        return None
+
+
+def _fir_mode():
+    """the FIR mode the profiled library runs by default (bl_amd_fir_mode), None without the library"""
+    import os
+    import sys
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bliss_amd
+        return int(bliss_amd.load().bl_amd_fir_mode())
+    except Exception:
+        return None
+
+
 def main(root, cmd, songs=SONGS):
     global SONGS
     SONGS = int(songs)
@@ -29,6 +49,8 @@ def main(root, cmd, songs=SONGS):
                 "INSTS/ACTIVE_INST_VALU and WAVE_CYCLES count in units of 4 cycles; VALU busy = "
                 "ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32.",
         "songs": SONGS,
+        "git_head": _read(".git_head"),
+        "fir_mode": _fir_mode(),
         "algorithmic_bytes_per_launch": algo,
         "kernels": {},
     }

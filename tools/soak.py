@@ -5,7 +5,11 @@ tempo / amplitude / attack to 1e-4 relative (north-star) and frequency / force w
 |x - y| <= 1e-5 + 1e-4 |y| (plus the absolute 1e-5 of the reference's own test, ref
 tests/test_analyze.c:30-35: they are differences of O(10) quantities and cross zero); prints a JSON
 summary.  Test infrastructure (uses oracle/).
-usage: python tools/soak.py [--songs 512] [--seed 1] [--max-seconds 40]"""
+usage: python tools/soak.py [--songs 512] [--seed 1] [--max-seconds 40]
+       python tools/soak.py --seconds 180 --rate 44100 --stereo --songs 1024     (the metric's own song shape)
+Songs are synthesised and analysed by the oracle in worker processes, chunk by chunk (a chunk of
+S180 songs is 4 GB of PCM), and each chunk goes through the HIP batch path as one resident batch.
+--fir-mode N sets BL_AMD_FIR_FUSED for the run."""
 import argparse
 import json
 import multiprocessing as mp
@@ -23,11 +27,16 @@ INTS = ("start", "end", "mean", "variance", "n_frames", "nb_frames", "n_windows"
 FLOATS = ("tempo", "amplitude", "frequency", "attack", "force")
 
 
-def make_song(seed, max_seconds):
+def make_song(seed, max_seconds, seconds=None, rate=None, channels=None):
+    """seconds / rate / channels: fixed values instead of the random draw (the draws are still
+    made, so that the rest of the song does not depend on which of them are fixed)."""
     rng = np.random.default_rng(seed)
-    rate = int(rng.choice([8000, 11025, 22050, 44100, 48000]))
-    ch = int(rng.integers(1, 3))
-    secs = float(rng.uniform(1.0, max_seconds))
+    r_rate = int(rng.choice([8000, 11025, 22050, 44100, 48000]))
+    r_ch = int(rng.integers(1, 3))
+    r_secs = float(rng.uniform(1.0, max_seconds))
+    rate = int(rate) if rate else r_rate
+    ch = int(channels) if channels else r_ch
+    secs = float(seconds) if seconds else r_secs
     frames = max(int(rate * secs), 5120 // ch + 1)
     n = frames * ch + int(rng.integers(0, 7))          # ragged tails
     t = np.arange(frames) / rate
@@ -61,14 +70,15 @@ def make_song(seed, max_seconds):
 _orc = None
 
 
-def _oracle_one(args):
+def _work(args):
+    """worker: synthesise one song and analyse it with the oracle"""
     global _orc
     if _orc is None:
         from oracle_py import Oracle
         _orc = Oracle()
-    seed, max_seconds = args
-    pcm, ch, dur = make_song(seed, max_seconds)
-    return seed, _orc.analyze(pcm, ch, dur)
+    seed, kw = args
+    pcm, ch, dur = make_song(seed, **kw)
+    return seed, pcm, ch, dur, _orc.analyze(pcm, ch, dur)
 
 
 def main():
@@ -76,50 +86,82 @@ def main():
     ap.add_argument("--songs", type=int, default=512)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-seconds", type=float, default=40.0)
+    ap.add_argument("--seconds", type=float, default=0.0, help="fixed length instead of 1..max-seconds")
+    ap.add_argument("--rate", type=int, default=0, help="fixed sample rate instead of the random one")
+    ap.add_argument("--stereo", action="store_true", help="always two channels")
+    ap.add_argument("--chunk", type=int, default=0, help="songs per resident batch (0: sized for ~6 GB of PCM)")
+    ap.add_argument("--fir-mode", type=int, default=-1, help="BL_AMD_FIR_FUSED for this run")
     ap.add_argument("--procs", type=int, default=0)
     a = ap.parse_args()
+    if a.fir_mode >= 0:
+        os.environ["BL_AMD_FIR_FUSED"] = str(a.fir_mode)
     import bliss_amd
+    kw = dict(max_seconds=a.max_seconds, seconds=a.seconds or None, rate=a.rate or None,
+              channels=2 if a.stereo else None)
     seeds = [a.seed * 1000003 + i for i in range(a.songs)]
-    t0 = time.time()
-    songs = [make_song(s, a.max_seconds) for s in seeds]
-    corpus = bliss_amd.DeviceCorpus([p.size for p, _, _ in songs], [c for _, c, _ in songs],
-                                    [d for _, _, d in songs])
-    for i, (p, _, _) in enumerate(songs):
-        corpus.upload(i, p)
-    corpus.analyze()
-    got = corpus.fetch()
-    t1 = time.time()
-    with mp.get_context("fork").Pool(a.procs or os.cpu_count()) as pool:
-        refs = dict(pool.imap_unordered(_oracle_one, [(s, a.max_seconds) for s in seeds], chunksize=1))
-    t2 = time.time()
+    est_bytes = 2 * 2 * (a.rate or 48000) * (a.seconds or a.max_seconds / 2)
+    chunk = a.chunk or max(16, min(1024, int(6e9 / est_bytes)))
+    procs = a.procs or os.cpu_count()
     bad_int, bad_float, not_bitwise, worst = [], [], 0, 0.0
     worst_by = {k: 0.0 for k in FLOATS}
     nbit_by = {k: 0 for k in FLOATS}
-    min_margin = 1e9
-    for i, s in enumerate(seeds):
-        r, g = refs[s], got[i]
-        min_margin = min(min_margin, r["min_peak_margin"])
-        for k in INTS:
-            if int(g[k]) != int(r[k]):
-                bad_int.append((s, k, int(g[k]), int(r[k])))
-        for k in FLOATS:
-            x, y = float(g[k]), float(r[k])
-            worst = max(worst, abs(x - y))
-            worst_by[k] = max(worst_by[k], abs(x - y))
-            # frequency / force: the reference's own absolute 1e-5 on top of the relative bound (they
-            # cross zero and go through an f32 DFT that is not the oracle's); the rest: strict relative
-            tol = 1e-5 + 1e-4 * abs(y) if k in ("frequency", "force") else 1e-4 * max(abs(y), 1e-6)
-            if abs(x - y) > tol:
-                bad_float.append((s, k, x, y))
-            if np.float32(x) != np.float32(y):
-                not_bitwise += 1
-                nbit_by[k] += 1
-    print(json.dumps({"songs": a.songs, "seed": a.seed, "int_mismatches": bad_int[:10],
+    margins, beats = [], []
+    t_gpu = t_cpu = 0.0
+    windows = 0
+    with mp.get_context("fork").Pool(procs) as pool:
+        for c0 in range(0, a.songs, chunk):
+            t0 = time.time()
+            part = sorted(pool.imap_unordered(_work, [(s, kw) for s in seeds[c0:c0 + chunk]], chunksize=1),
+                          key=lambda r: r[0])
+            t1 = time.time()
+            corpus = bliss_amd.DeviceCorpus([p.size for _, p, _, _, _ in part], [c for _, _, c, _, _ in part],
+                                            [d for _, _, _, d, _ in part])
+            for i, (_, p, _, _, _) in enumerate(part):
+                corpus.upload(i, p)
+            corpus.analyze()
+            got = corpus.fetch()
+            t2 = time.time()
+            t_cpu += t1 - t0
+            t_gpu += t2 - t1
+            for i, (s, _, _, _, r) in enumerate(part):
+                g = got[i]
+                margins.append(float(r["min_peak_margin"]))
+                beats.append(int(r["beat"]))
+                windows += int(r["n_windows"])
+                for k in INTS:
+                    if int(g[k]) != int(r[k]):
+                        bad_int.append((s, k, int(g[k]), int(r[k])))
+                for k in FLOATS:
+                    x, y = float(g[k]), float(r[k])
+                    worst = max(worst, abs(x - y))
+                    worst_by[k] = max(worst_by[k], abs(x - y))
+                    # frequency / force: the reference's own absolute 1e-5 on top of the relative bound (they
+                    # cross zero and go through an f32 DFT that is not the oracle's); the rest: strict relative
+                    tol = 1e-5 + 1e-4 * abs(y) if k in ("frequency", "force") else 1e-4 * max(abs(y), 1e-6)
+                    if abs(x - y) > tol:
+                        bad_float.append((s, k, x, y))
+                    if np.float32(x) != np.float32(y):
+                        not_bitwise += 1
+                        nbit_by[k] += 1
+            del corpus, part
+    m = np.sort(np.asarray(margins))
+    pct = {f"p{q}": float(np.percentile(m, q)) for q in (0.1, 1, 10, 50, 90)} if m.size else {}
+    print(json.dumps({"songs": a.songs, "seed": a.seed,
+                      "shape": {"seconds": a.seconds or f"1..{a.max_seconds}", "rate": a.rate or "random",
+                                "channels": 2 if a.stereo else "random"},
+                      "fir_mode": os.environ.get("BL_AMD_FIR_FUSED", "default"),
+                      "int_mismatches": bad_int[:10],
                       "n_int_mismatches": len(bad_int), "float_out_of_tolerance": bad_float[:10],
                       "n_float_out_of_tolerance": len(bad_float), "float_fields_not_bit_identical": not_bitwise,
-                      "worst_abs_err": worst, "worst_abs_err_by_field": worst_by, "not_bit_identical_by_field": nbit_by, "min_peak_margin": min_margin,
-                      "gpu_seconds_incl_synthesis_and_upload": round(t1 - t0, 2),
-                      "oracle_seconds": round(t2 - t1, 2), "procs": a.procs or os.cpu_count(),
+                      "worst_abs_err": worst, "worst_abs_err_by_field": worst_by, "not_bit_identical_by_field": nbit_by,
+                      "windows": windows, "peak_decisions": 2 * windows,
+                      "beat_min_median_max": [int(np.min(beats)), int(np.median(beats)), int(np.max(beats))],
+                      "min_peak_margin": float(m[0]) if m.size else None,
+                      "min_peak_margin_percentiles": pct,
+                      "songs_with_margin_below": {f"{t:g}": int(np.count_nonzero(m < t))
+                                                  for t in (1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7)},
+                      "gpu_seconds_incl_upload": round(t_gpu, 2),
+                      "synthesis_and_oracle_seconds": round(t_cpu, 2), "procs": procs, "chunk": chunk,
                       "tolerance": "ints exact; tempo/amplitude/attack 1e-4 rel; frequency/force 1e-5 + 1e-4 |ref|"}))
     return 1 if (bad_int or bad_float) else 0
 
