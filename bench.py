@@ -283,10 +283,7 @@ def plumbing_only(args):
                           "ms_per_step": 1e3 * elapsed / max(args.steps + args.warmup, 1),
                           "config": {"workload": f"{songs} stand-in vectors per rank, {total} total",
                                      "parallelism": f"shard{world}"},
-                          "memory": {"free_bytes_before_alloc": int(free_b), "total_bytes": int(total_b),
-                       "free_bytes_after_alloc": int(mem_after_alloc[0]),
-                       "row_block_bytes": 4 * songs * cols, "emulated_world": args.emulate_world or None},
-            "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
+                          "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                                          "all_gather_calls": gathers if dist.is_initialized() else 0,
                                          "bytes_per_rank": 16 * songs},
                           "results_ok": ok}), flush=True)
@@ -505,6 +502,18 @@ def main():
         torch.cuda.synchronize(dev)
         dm_s = (time.perf_counter() - t1) / reps
         dm_bytes = 4 * 10000 * 10000 + 16 * 10000
+        # its sibling on the same vectors: the 10 000 x 10 000 bl_cosine_similarity matrix
+        # (ref src/analyze.c:127-143; f32 dot and norms, double sqrt, product and divide)
+        for _ in range(2):
+            lib.bl_amd_cosine_matrix_device(C.c_void_p(v10.data_ptr()), 10000, 0, 10000,
+                                            C.c_void_p(m10.data_ptr()), stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            lib.bl_amd_cosine_matrix_device(C.c_void_p(v10.data_ptr()), 10000, 0, 10000,
+                                            C.c_void_p(m10.data_ptr()), stream)
+        torch.cuda.synchronize(dev)
+        cm_s = (time.perf_counter() - t1) / reps
 
         line = {
             "metric": "songs/sec bl_analyze (3-min 44.1kHz s16) + 10k x 10k distance-matrix sec",
@@ -521,12 +530,17 @@ def main():
             "distance_matrix_10k_s": dm_s,
             "distance_matrix_10k_gbs": dm_bytes / dm_s / 1e9,
             "distance_matrix_10k_frac_hbm": dm_bytes / dm_s / 1e9 / HBM_PEAK_GBS,
+            "cosine_matrix_10k_s": cm_s,
+            "cosine_matrix_10k_frac_hbm": dm_bytes / cm_s / 1e9 / HBM_PEAK_GBS,
             "whole_path_algorithmic_gbs_per_gpu": whole_path_gbs,
             "whole_path_frac_hbm": whole_path_gbs / HBM_PEAK_GBS,
             "kernels_ms": kern, "results_ok": ok, "verified_songs": verified,
             "verification": {"against": "CPU oracle (oracle/orc_cli) on the re-synthesised songs, untimed",
                              "bar": "integers identical, f32 features <= 1e-4 relative",
                              "songs": verify_details},
+            "memory": {"free_bytes_before_alloc": int(free_b), "total_bytes": int(total_b),
+                       "free_bytes_after_alloc": int(mem_after_alloc[0]),
+                       "row_block_bytes": 4 * songs * cols, "emulated_world": args.emulate_world or None},
             "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                            "all_gather_calls": n_gathers[0] if dist.is_initialized() else 0,
                            "bytes_per_rank": 16 * songs},

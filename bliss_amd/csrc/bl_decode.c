@@ -76,6 +76,8 @@ typedef struct {
   size_t n, cap;
   int wide;
   int is_float; /* wide only: p32 holds IEEE float bit patterns (RIFF format tag 3) */
+  int non_s16;  /* the source's sample format is not S16 for FFmpeg (u8, 24 / 32 bit, float): the
+                 * reference sends such a file through libswresample even at 22 050 Hz */
   uint32_t bps; /* significant bits of the source */
 } pcm_sink;
 
@@ -108,6 +110,11 @@ static void sink_free(pcm_sink *s) {
 }
 
 static int wants_rate_conversion(uint32_t rate);
+/* keep all 32 bits: the source is wider than 16 bits and a float stage follows — the rate
+ * converter, or the mono up-mix of a same-rate file (bl_audio_decode) */
+static int wants_wide(uint32_t bits, uint32_t rate, uint32_t channels) {
+  return bits > 16 && (wants_rate_conversion(rate) || (channels == 1 && !native_rate_allowed()));
+}
 
 /* ----------------------------------------------------------------------- */
 typedef struct {
@@ -225,8 +232,9 @@ static int decode_wav(const uint8_t *d, size_t len, struct bl_song *song, pcm_si
       if (n == 0) return BL_UNEXPECTED;
       /* 8-bit PCM is unsigned; as s16 it is (v - 128) << 8, the conversion every 16-bit path starts from */
       sink->bps = bits == 8 ? 16 : bits;
-      sink->wide = bits > 16 && wants_rate_conversion(rate);
+      sink->wide = wants_wide(bits, rate, channels);
       sink->is_float = is_float && sink->wide;
+      sink->non_s16 = bits != 16;
       if (sink_reserve(sink, n)) return BL_UNEXPECTED;
       for (uint32_t i = 0; i < n; ++i) {
         const uint8_t *q = body + (size_t)bytes * i;
@@ -535,7 +543,8 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
   size_t audio_start = pos;
 
   sink->bps = fi.bps;
-  sink->wide = fi.bps > 16 && wants_rate_conversion(fi.rate);
+  sink->wide = wants_wide(fi.bps, fi.rate, fi.channels);
+  sink->non_s16 = fi.bps > 16; /* FFmpeg's FLAC decoder delivers S16 up to 16 bits, S32 above */
   if (sink_reserve(sink, fi.total ? (size_t)fi.total * fi.channels / 2 + 8 : (size_t)1 << 19))
     return BL_UNEXPECTED;
   uint32_t maxb = fi.max_block ? fi.max_block : 65535;
@@ -701,9 +710,55 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
       song->sample_rate = BL_DECODE_RATE;
       song->resampled = 1;
     }
-  } else if (rc == BL_OK) {
+  } else if (rc == BL_OK && native_rate_allowed()) { /* the caller's own business: as decoded */
     song->sample_array = (int8_t *)sink.p16;
     sink.p16 = NULL;
+  } else if (rc == BL_OK) {
+    /* 22 050 Hz already.  ref src/decode.c:312-346: a source whose sample format is not S16 still
+     * goes through libswresample (resampled = 1): no filter at equal rates, but the format
+     * conversion — S32 -> S16 is >> 16, FLT -> S16 lrintf(x * 2^15) clipped, both done while the
+     * samples were stored — and, for a mono source, the up-mix to the stereo output layout with
+     * gain 1/sqrt(2): in float for wide sources (S32 -> FLT * 2^-31, times the float coefficient,
+     * FLT -> S16), in Q15 for an 8-bit one.  Third-party arithmetic (libswresample), restated
+     * from its published conversion functions: parity unpinned — the reference holds no vector
+     * of a same-rate non-S16 file. */
+    if (sink.non_s16) song->resampled = 1;
+    if (sink.non_s16 && song->channels == 1) {
+      const size_t n = sink.n;
+      int16_t *o = n <= (size_t)INT32_MAX / 2 ? (int16_t *)malloc(2 * n * sizeof(int16_t) + 16) : NULL;
+      if (!o) {
+        rc = BL_UNEXPECTED;
+      } else {
+        const float g = (float)M_SQRT1_2;
+        for (size_t i = 0; i < n; ++i) {
+          int16_t v;
+          if (sink.wide) {
+            float x;
+            if (sink.is_float) {
+              memcpy(&x, &sink.p32[i], sizeof x);
+              if (!(x == x) || x > 4.0f || x < -4.0f) x = x > 0 ? 4.0f : (x < 0 ? -4.0f : 0.0f);
+            } else {
+              x = (float)sink.p32[i] * (1.0f / 2147483648.0f);
+            }
+            const long r = lrintf(x * g * 32768.0f);
+            v = (int16_t)(r > 32767 ? 32767 : r < -32768 ? -32768 : r);
+          } else {
+            v = (int16_t)(((int32_t)sink.p16[i] * 23170 + 16384) >> 15);
+          }
+          o[2 * i] = o[2 * i + 1] = v;
+        }
+        song->sample_array = (int8_t *)o;
+        song->nSamples = (int)(2 * n);
+      }
+    } else {
+      song->sample_array = (int8_t *)sink.p16;
+      sink.p16 = NULL;
+    }
+    /* ref src/decode.c:191-193: the reference reports two channels whatever the file has.  A mono
+     * S16 file at 22 050 Hz is the one case in which that is not true of its samples (no
+     * converter ran): the reference's analyzers then read them as interleaved pairs, and so do
+     * ours — same numbers, which is what a drop-in owes. */
+    song->channels = 2;
   }
   sink_free(&sink);
   if (rc != BL_OK) {

@@ -36,6 +36,7 @@
 #include <string.h>
 
 #include "bl_launch.h"
+#include "bl_sqrt.h"
 #include "bl_tail.h"
 
 #define BL_HIP_CHECK(expr)                                                              \
@@ -1490,11 +1491,15 @@ __global__ void k_force(bl_amd_song_result *res, int n_songs) {
 /* ------------------------------------------------------------------------- */
 /* k_pairwise                                                                 */
 
-__device__ __forceinline__ float bl_dist(const float4 a, const float4 b) {
-  /* ref analyze.c:96-100: f32 throughout, left-to-right, sqrt correctly rounded */
+/* ref analyze.c:96-100: f32 throughout, left-to-right; the sum whose root bl_distance returns */
+__device__ __forceinline__ float bl_dist_sq(const float4 a, const float4 b) {
   const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-  const float s = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-  return sqrtf(s); /* correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the 1-ulp native op */
+  return d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+}
+
+__device__ __forceinline__ float bl_dist(const float4 a, const float4 b) {
+  /* sqrt correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the 1-ulp native op */
+  return sqrtf(bl_dist_sq(a, b));
 }
 
 __device__ __forceinline__ float bl_cos(const float4 a, const float4 b) {
@@ -1526,13 +1531,61 @@ __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vec
     const float4 a = vecs[row_begin + row];
     float *orow = out + (size_t)row * n;
     float r[4];
+    if (COSINE) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = COSINE ? bl_cos(a, b[k]) : bl_dist(a, b[k]);
+      for (int k = 0; k < 4; ++k) r[k] = bl_cos(a, b[k]);
+    } else {
+      /* the five-instruction root where every sum of the wave is in its domain (bl_sqrt.h), the
+       * compiler's sqrtf otherwise: a zero (the diagonal, duplicate songs), a tiny or a non-finite
+       * sum — about one wave-row in forty at N = 10 000.  Both are the correctly rounded root. */
+      float q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = bl_dist_sq(a, b[k]);
+      const float lo = fminf(fminf(q[0], q[1]), fminf(q[2], q[3]));
+      const float hi = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+      if (__all(bl_sqrt_fast_ok(lo) && bl_sqrt_fast_ok(hi))) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = bl_sqrt_rn_fast(q[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = sqrtf(q[k]);
+      }
+    }
     if (vec_ok) {
       *reinterpret_cast<float4 *>(orow + j0) = make_float4(r[0], r[1], r[2], r[3]);
     } else {
       for (int k = 0; k < 4 && j0 + k < n; ++k) orow[j0 + k] = r[k];
     }
+  }
+}
+
+/* Exhaustive check of bl_sqrt_rn_fast: every f32 bit pattern in [first, first + count) that lies
+ * in the fast domain against (float)sqrt((double)s); counts[0] += values checked, counts[1] +=
+ * mismatches, counts[2] += mismatches of the compiler's sqrtf over ALL patterns of the range
+ * (zero, denormals, infinities included; NaN results compare equal to NaN). */
+__global__ __launch_bounds__(256) void k_sqrt_sweep(unsigned long long first, unsigned long long count,
+                                                    unsigned long long *counts) {
+  unsigned long long checked = 0, bad_fast = 0, bad_slow = 0;
+  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < count; i += gridDim.x * 256ull) {
+    const float s = __uint_as_float((unsigned)(first + i));
+    const float want = (float)sqrt((double)s);
+    const float slow = sqrtf(s);
+    if (!(slow == want || (slow != slow && want != want))) ++bad_slow;
+    if (bl_sqrt_fast_ok(s)) {
+      ++checked;
+      if (__float_as_uint(bl_sqrt_rn_fast(s)) != __float_as_uint(want)) ++bad_fast;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    checked += __shfl_down(checked, off);
+    bad_fast += __shfl_down(bad_fast, off);
+    bad_slow += __shfl_down(bad_slow, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], checked);
+    atomicAdd(&counts[1], bad_fast);
+    atomicAdd(&counts[2], bad_slow);
   }
 }
 
@@ -1865,6 +1918,13 @@ int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int 
       hipLaunchKernelGGL(k_pairwise<false>, dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
   }
+  BL_HIP_CHECK(hipGetLastError());
+  return BL_OK;
+}
+
+int blk_sqrt_sweep(hipStream_t s, unsigned long long first, unsigned long long count,
+                   unsigned long long *d_counts, int n_cu) {
+  hipLaunchKernelGGL(k_sqrt_sweep, dim3(n_cu * 8), dim3(256), 0, s, first, count, d_counts);
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }

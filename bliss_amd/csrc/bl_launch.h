@@ -92,6 +92,10 @@ int blk_synth(hipStream_t s, int16_t *pcm, const bl_dsong *d_songs, int n_songs,
               int n_cu, unsigned seed_base, unsigned rate);
 int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int row_begin,
                  int n_rows, float *d_out, bool cosine, blk_mark_fn mark, void *mark_user);
+/* exhaustive self-test of bl_sqrt.h over f32 bit patterns [first, first + count): d_counts[0..2] +=
+ * values in the fast domain, mismatches of the fast root, mismatches of the compiler's sqrtf */
+int blk_sqrt_sweep(hipStream_t s, unsigned long long first, unsigned long long count,
+                   unsigned long long *d_counts, int n_cu);
 int blk_playlist(hipStream_t s, const struct force_vector_s *d_vecs, int n, int seed_index,
                  int32_t *d_order, float *d_dist);
 /* out[i] = (int16)(in[i] >> 16): the same-rate S32 -> S16 narrowing */

@@ -836,6 +836,25 @@ int bl_amd_playlist_host(const struct force_vector_s *h_vecs, int n, int seed_in
   return rc;
 }
 
+int bl_amd_selftest_sqrt(uint64_t counts[3]) {
+  if (!counts) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  DevGuard dg(c->device);
+  unsigned long long *d = nullptr;
+  BL_HIP_CHECK(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+  int rc = BL_UNEXPECTED;
+  unsigned long long h[3] = {0, 0, 0};
+  if (hipMemset(d, 0, sizeof h) == hipSuccess &&
+      blk_sqrt_sweep(nullptr, 0ull, 1ull << 32, d, c->n_cu) == BL_OK &&   /* every f32 bit pattern */
+      hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+    for (int k = 0; k < 3; ++k) counts[k] = h[k];
+    rc = BL_OK;
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
 static int matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out, bool cosine) {
   if (n <= 0 || !h_vecs || !h_out) return BL_UNEXPECTED;
   bl_amd_ctx *c = blr_default_ctx();

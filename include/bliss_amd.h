@@ -125,7 +125,11 @@ int bl_amd_narrow_s32_device(const int32_t *d_in, int16_t *d_out, size_t n, void
 /* Rate conversion to the analyzers' 22 050 Hz stereo s16 — the arithmetic bl_audio_decode()
  * applies to a file at another rate (a restatement of libswresample's default resampler that
  * reproduces the digests of ref tests/test_decode.c:35-36,55-56), for
- * callers that bring their own decoder.  `in`: interleaved frames of 1 or 2 channels at in_rate
+ * callers that bring their own decoder.  PARITY: only the path for sources wider than 16 bits is
+ * pinned on the reference's digests; the 16-bit (Q15) path — what a 44.1 kHz s16 collection goes
+ * through — is parity unpinned (s16 path): no reference vector covers its rounding, and every
+ * throughput figure quoted for it is a figure for this restatement.
+ * `in`: interleaved frames of 1 or 2 channels at in_rate
  * Hz, int16, or (in_is_s32 = 1) int32 left-justified, or — host form only — (in_is_s32 = 2)
  * float with full scale +-1.  A mono source comes out as two equal
  * channels at gain 1/sqrt(2), as the reference's out layout does.
@@ -213,6 +217,13 @@ int bl_amd_cosine_matrix_device(const struct force_vector_s *d_vecs, int n, int 
 /* Host-pointer conveniences (blocking). */
 int bl_amd_distance_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out);
 int bl_amd_cosine_matrix_host(const struct force_vector_s *h_vecs, int n, float *h_out);
+
+/* Self-test of the square root inside the bl_distance kernels (bliss_amd/csrc/bl_sqrt.h): runs it
+ * over every f32 bit pattern on the device and compares with the correctly rounded root,
+ * (float)sqrt((double)s).  counts[0] = values in the domain of the five-instruction form,
+ * counts[1] = its mismatches, counts[2] = mismatches of the fallback (the compiler's correctly
+ * rounded sqrtf) over all 2^32 patterns.  Both must be 0 (tests/test_gpu_parity.py). */
+int bl_amd_selftest_sqrt(uint64_t counts[3]);
 
 /* Seeded playlist (ref python/examples/make_m3u_playlist.py:62-72): d_dist[j] =
  * bl_distance(vecs[seed_index], vecs[j]) and d_order = the song indices by increasing

@@ -433,3 +433,15 @@ def test_batches_on_two_streams_do_not_race(gpu_lib, oracle):
     for i in range(6):
         check_song(ra[i], oracle.analyze(pcm_a[i], 2, 8), ("stream1", i))
         check_song(rb[i], oracle.analyze(pcm_b[i], 1, 9), ("stream2", i))
+
+
+def test_sqrt_of_the_distance_kernels_is_correctly_rounded(gpu_lib):
+    """bl_distance's root (ref src/analyze.c:96-100, an IEEE sqrt): the five-instruction form of
+    bliss_amd/csrc/bl_sqrt.h over EVERY f32 bit pattern of its domain, and the fallback over all
+    2^32 patterns, against (float)sqrt((double)s) on the device — no mismatch anywhere."""
+    counts = (C.c_uint64 * 3)()
+    assert gpu_lib.bl_amd_selftest_sqrt(counts) == 0
+    checked, bad_fast, bad_slow = int(counts[0]), int(counts[1]), int(counts[2])
+    # [2^-100, 2^126]: 226 binades of 2^23 values and the upper end point
+    assert checked == 226 * (1 << 23) + 1, checked
+    assert bad_fast == 0 and bad_slow == 0, (bad_fast, bad_slow)

@@ -34,9 +34,10 @@ def _crc16(data):
     return c
 
 
-def write_flac_verbatim(path, samples, channels, rate, bps, comment_block=None):
-    """Minimal FLAC writer (VERBATIM subframes, independent channels, one frame per 4096
-    samples): test input for the decoder, bit depth 16 or 24."""
+def write_flac_verbatim(path, samples, channels, rate, bps, comment_block=None, stereo_mode=None):
+    """Minimal FLAC writer (VERBATIM subframes, one frame per 4096 samples): test input for the
+    decoder, bit depth 16, 24 or 32; independent channels, or (stereo_mode="left_side") the left
+    channel and a side channel left - right of bps + 1 bits."""
     samples = np.asarray(samples, dtype=np.int64).reshape(-1, channels)
     total = samples.shape[0]
     nb = bps // 8
@@ -52,13 +53,13 @@ def write_flac_verbatim(path, samples, channels, rate, bps, comment_block=None):
     for i, (t, body) in enumerate(blocks):
         last = 0x80 if i == len(blocks) - 1 else 0
         out += bytes([last | t]) + len(body).to_bytes(3, "big") + body
-    ss_code = {16: 4, 24: 6}[bps]
+    ss_code = {16: 4, 24: 6, 32: 7}[bps]
     for fno, start in enumerate(range(0, total, 4096)):
         blk = samples[start:start + 4096]
         bs = blk.shape[0]
         hdr = bytearray([0xFF, 0xF8])
         hdr.append((7 << 4) | 0)                       # blocksize: 16-bit field follows; rate: from STREAMINFO
-        hdr.append(((channels - 1) << 4) | (ss_code << 1))
+        hdr.append(((8 if stereo_mode == "left_side" else channels - 1) << 4) | (ss_code << 1))
         assert fno < 128
         hdr.append(fno)                                # UTF-8 coded frame number (1 byte)
         hdr += (bs - 1).to_bytes(2, "big")
@@ -66,8 +67,10 @@ def write_flac_verbatim(path, samples, channels, rate, bps, comment_block=None):
         bits = []
         for c in range(channels):
             bits.append("0" + "000001" + "0")          # padding, VERBATIM, no wasted bits
-            for v in blk[:, c]:
-                bits.append(format(int(v) & ((1 << bps) - 1), "0%db" % bps))
+            side = stereo_mode == "left_side" and c == 1
+            w = bps + 1 if side else bps
+            for v in (blk[:, 0] - blk[:, 1] if side else blk[:, c]):
+                bits.append(format(int(v) & ((1 << w) - 1), "0%db" % w))
         s = "".join(bits)
         s += "0" * (-len(s) % 8)
         frame = bytes(hdr) + int(s, 2).to_bytes(len(s) // 8, "big")
@@ -277,7 +280,9 @@ def test_wav_float_and_8_bit(lib, tmp_path):
     p = tmp_path / "f.wav"
     _wav(p, 3, 2, 22050, 32, x.tobytes())
     rc, pcm, meta = _decode(lib, p)
-    assert rc == _lib.BL_OK and meta["rate"] == 22050 and meta["resampled"] == 0
+    # not an S16 source: the reference routes it through libswresample even at 22 050 Hz (ref
+    # src/decode.c:312-321), so resampled = 1 although no rate changes
+    assert rc == _lib.BL_OK and meta["rate"] == 22050 and meta["resampled"] == 1 and meta["channels"] == 2
     clean = np.where(np.isnan(x), 0.0, np.clip(x, -4.0, 4.0)).astype(np.float32)
     want = np.clip(np.rint(clean * np.float32(32768.0)), -32768, 32767).astype(np.int16)
     assert np.array_equal(pcm, want)
@@ -299,6 +304,76 @@ def test_wav_float_and_8_bit(lib, tmp_path):
     rc, c, _ = _decode(lib, p)
     import bliss_amd
     assert rc == _lib.BL_OK and np.array_equal(c, bliss_amd.resample_host(((u8.astype(np.int32) - 128) * 256).astype(np.int16), 2, 44100))
+
+
+def test_same_rate_sources_follow_the_reference_layout(lib, tmp_path):
+    """ref src/decode.c:191-193,312-346 at 22 050 Hz: every decoded song reports two channels; a
+    source that is not S16 counts as resampled, and a MONO one of those is up-mixed to stereo with
+    gain 1/sqrt(2) (float for wide sources, Q15 for 8 bit) — libswresample's arithmetic restated,
+    parity unpinned; a mono S16 file is handed over as it is (and read as interleaved pairs, as
+    the reference reads it)."""
+    rng = np.random.default_rng(21)
+    n = 9000
+    g = np.float32(np.sqrt(0.5))
+    # mono 24-bit FLAC
+    s24 = rng.integers(-(1 << 23), 1 << 23, n)
+    p = tmp_path / "m24.flac"
+    write_flac_verbatim(p, s24, 1, 22050, 24)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["channels"] == 2 and meta["resampled"] == 1 and pcm.size == 2 * n
+    x = (s24.astype(np.int64) << 8).astype(np.float32) * np.float32(1.0 / 2147483648.0)
+    want = np.clip(np.rint((x * g) * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+    assert np.array_equal(pcm[0::2], want) and np.array_equal(pcm[1::2], want)
+    # mono float WAV
+    f = rng.uniform(-1.1, 1.1, n).astype(np.float32)
+    w = tmp_path / "m.wav"
+    _wav(w, 3, 1, 22050, 32, f.tobytes())
+    rc, pcm, meta = _decode(lib, w)
+    want = np.clip(np.rint((f * g) * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+    assert rc == _lib.BL_OK and meta["resampled"] == 1 and np.array_equal(pcm[0::2], want) and np.array_equal(pcm[1::2], want)
+    # mono 8-bit WAV: Q15 up-mix of (v - 128) << 8
+    u8 = rng.integers(0, 256, n).astype(np.uint8)
+    _wav(w, 1, 1, 22050, 8, u8.tobytes())
+    rc, pcm, meta = _decode(lib, w)
+    v = (u8.astype(np.int32) - 128) * 256
+    want = ((v * 23170 + 16384) >> 15).astype(np.int16)
+    assert rc == _lib.BL_OK and meta["resampled"] == 1 and np.array_equal(pcm[0::2], want) and np.array_equal(pcm[1::2], want)
+    # mono S16: untouched samples, two channels reported, not resampled
+    s16 = rng.integers(-32768, 32768, n)
+    write_flac_verbatim(p, s16, 1, 22050, 16)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["channels"] == 2 and meta["resampled"] == 0
+    assert np.array_equal(pcm, s16.astype(np.int16))
+    # stereo 24-bit at 22 050 Hz: >> 16 of the left-justified word, resampled = 1
+    s24 = rng.integers(-(1 << 23), 1 << 23, 2 * n)
+    write_flac_verbatim(p, s24, 2, 22050, 24)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and meta["resampled"] == 1 and np.array_equal(pcm, ((s24 << 8) >> 16).astype(np.int16))
+
+
+def test_32bit_flac_side_channel_is_refused(lib, tmp_path, capfd):
+    """A 32-bit stereo FLAC frame with inter-channel decorrelation carries a 33-bit side channel:
+    refused loudly (the frame CRCs would pass on wrongly decoded samples); independent channels
+    at 32 bits decode."""
+    rng = np.random.default_rng(22)
+    s32 = rng.integers(-(1 << 31), 1 << 31, 2 * 5000)
+    p = tmp_path / "v32.flac"
+    md5 = write_flac_verbatim(p, s32, 2, 22050, 32)
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and np.array_equal(pcm, (s32 >> 16).astype(np.int16))
+    got = (C.c_uint8 * 16)()
+    assert lib.bl_amd_flac_verify(str(p).encode(), got, None) == 1 and bytes(got) == md5
+    write_flac_verbatim(p, s32, 2, 22050, 32, stereo_mode="left_side")
+    capfd.readouterr()
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_UNEXPECTED
+    assert "32-bit FLAC with inter-channel decorrelation" in capfd.readouterr().err
+    # the same coding at 24 bits (a 25-bit side channel) decodes to the right samples
+    s24 = rng.integers(-(1 << 23), 1 << 23, 2 * 5000)
+    md5 = write_flac_verbatim(p, s24, 2, 22050, 24, stereo_mode="left_side")
+    rc, pcm, meta = _decode(lib, p)
+    assert rc == _lib.BL_OK and np.array_equal(pcm, ((s24 << 8) >> 16).astype(np.int16))
+    assert lib.bl_amd_flac_verify(str(p).encode(), got, None) == 1 and bytes(got) == md5
 
 
 def test_malformed_vorbis_comment_lengths(lib, tmp_path):

@@ -76,6 +76,7 @@ def main():
                 assert abs(float(r[k][i]) - o[k]) <= 1e-4 * max(1.0, abs(o[k])), (i, k)
             verified += 1
     print(json.dumps(dict(tool="pipeline_bench", songs=n, seconds=args.seconds, in_rate=rate, kind="s16 stereo",
+                          parity="parity unpinned (s16 path): the converter's Q15 arithmetic has no reference vector",
                           convert_ms=round(t_conv, 2), analyze_ms=round(t_all - t_conv, 2), total_ms=round(t_all, 2),
                           songs_per_s=round(n / t_all * 1e3, 1), results_ok=ok, verified_songs=verified,
                           verification="host converter + CPU oracle; converter output bit-exact, integers exact, floats 1e-4 rel")))
