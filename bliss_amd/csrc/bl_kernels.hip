@@ -1515,7 +1515,11 @@ __device__ __forceinline__ float bl_cos(const float4 a, const float4 b) {
  * loads), so a vector is fetched once per 16 outputs instead of once per output and the
  * index arithmetic is paid once.  Output: 16-byte stores, each row segment contiguous. */
 #define BL_PW_ROWS 16
-template <bool COSINE>
+#ifndef BL_SQRT_VARIANT
+#define BL_SQRT_VARIANT 1
+#endif
+/* SQ: 0 = the compiler's correctly rounded sqrtf everywhere, 1 / 2 = bl_sqrt_rn_fast<SQ> in its domain */
+template <bool COSINE, int SQ = BL_SQRT_VARIANT>
 __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vecs, int n,
                                                   int row_begin, int n_rows,
                                                   float *__restrict__ out) {
@@ -1531,7 +1535,10 @@ __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vec
     const float4 a = vecs[row_begin + row];
     float *orow = out + (size_t)row * n;
     float r[4];
-    if (COSINE) {
+    if (SQ == 3) { /* measurement aid (BL_AMD_SQRT_VARIANT=3): the store stream alone, no arithmetic */
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = a.x;
+    } else if (COSINE) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[k] = bl_cos(a, b[k]);
     } else {
@@ -1541,17 +1548,17 @@ __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vec
       float q[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) q[k] = bl_dist_sq(a, b[k]);
-      const float lo = fminf(fminf(q[0], q[1]), fminf(q[2], q[3]));
-      const float hi = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
-      if (__all(bl_sqrt_fast_ok(lo) && bl_sqrt_fast_ok(hi))) {
+      const unsigned worst = max(max(bl_sqrt_fast_key(q[0]), bl_sqrt_fast_key(q[1])),
+                                 max(bl_sqrt_fast_key(q[2]), bl_sqrt_fast_key(q[3])));
+      if (SQ != 0 && __all(worst <= BL_SQRT_FAST_SPAN)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = bl_sqrt_rn_fast(q[k]);
+        for (int k = 0; k < 4; ++k) r[k] = bl_sqrt_rn_fast<SQ == 2 ? 2 : 1>(q[k]);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = sqrtf(q[k]);
       }
     }
-    if (vec_ok) {
+    if (vec_ok) { /* plain stores: with the non-temporal hint the same stream is 6 % slower (70.8 vs 66.6 us) */
       *reinterpret_cast<float4 *>(orow + j0) = make_float4(r[0], r[1], r[2], r[3]);
     } else {
       for (int k = 0; k < 4 && j0 + k < n; ++k) orow[j0 + k] = r[k];
@@ -1563,6 +1570,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vec
  * in the fast domain against (float)sqrt((double)s); counts[0] += values checked, counts[1] +=
  * mismatches, counts[2] += mismatches of the compiler's sqrtf over ALL patterns of the range
  * (zero, denormals, infinities included; NaN results compare equal to NaN). */
+template <int V>
 __global__ __launch_bounds__(256) void k_sqrt_sweep(unsigned long long first, unsigned long long count,
                                                     unsigned long long *counts) {
   unsigned long long checked = 0, bad_fast = 0, bad_slow = 0;
@@ -1573,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_sqrt_sweep(unsigned long long first, un
     if (!(slow == want || (slow != slow && want != want))) ++bad_slow;
     if (bl_sqrt_fast_ok(s)) {
       ++checked;
-      if (__float_as_uint(bl_sqrt_rn_fast(s)) != __float_as_uint(want)) ++bad_fast;
+      if (__float_as_uint(bl_sqrt_rn_fast<V>(s)) != __float_as_uint(want)) ++bad_fast;
     }
   }
 #pragma unroll
@@ -1793,6 +1801,16 @@ extern "C" int bl_amd_set_fir_mode(int mode) {
 
 namespace {
 
+/* measurement aid: BL_AMD_SQRT_VARIANT=0|1|2|3 picks the root of the distance kernel at run time
+ * (0 = the compiler's sqrtf only, 3 = no arithmetic at all: the store stream alone — results
+ * invalid); unset = the compiled default BL_SQRT_VARIANT.  rocprofv3 at N = 10 000, us per launch:
+ * 78.9 / 71.2 / 70.7 / 66.6 (tools/dist_bench.py, profiles/r03_distance.json). */
+int blk_sqrt_variant() {
+  const char *e = getenv("BL_AMD_SQRT_VARIANT");
+  const int v = e && *e ? atoi(e) : BL_SQRT_VARIANT;
+  return v < 0 || v > 3 ? BL_SQRT_VARIANT : v;
+}
+
 int grid_x_for(long long units_max, int n_songs, int blocks_per_cu, int n_cu) {
   /* enough blocks to fill the chip several times over, never more than the
    * longest song has work for */
@@ -1911,11 +1929,21 @@ int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int 
     const int cnt = n_rows - r0 < chunk ? n_rows - r0 : chunk;
     const int gy = (cnt + BL_PW_ROWS - 1) / BL_PW_ROWS;
     Mark m(mark, mark_user, PK_DIST, s);
+    const int sq = blk_sqrt_variant();
     if (cosine)
-      hipLaunchKernelGGL(k_pairwise<true>, dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
+      hipLaunchKernelGGL((k_pairwise<true, 0>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
+                         d_out + (size_t)r0 * n);
+    else if (sq == 0)
+      hipLaunchKernelGGL((k_pairwise<false, 0>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
+                         d_out + (size_t)r0 * n);
+    else if (sq == 3)
+      hipLaunchKernelGGL((k_pairwise<false, 3>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
+                         d_out + (size_t)r0 * n);
+    else if (sq == 2)
+      hipLaunchKernelGGL((k_pairwise<false, 2>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
     else
-      hipLaunchKernelGGL(k_pairwise<false>, dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
+      hipLaunchKernelGGL((k_pairwise<false, 1>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
   }
   BL_HIP_CHECK(hipGetLastError());
@@ -1924,7 +1952,10 @@ int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int 
 
 int blk_sqrt_sweep(hipStream_t s, unsigned long long first, unsigned long long count,
                    unsigned long long *d_counts, int n_cu) {
-  hipLaunchKernelGGL(k_sqrt_sweep, dim3(n_cu * 8), dim3(256), 0, s, first, count, d_counts);
+  if (blk_sqrt_variant() == 2)
+    hipLaunchKernelGGL(k_sqrt_sweep<2>, dim3(n_cu * 8), dim3(256), 0, s, first, count, d_counts);
+  else /* variant 0 ships no fast form; the sweep then checks form 1 and the fallback */
+    hipLaunchKernelGGL(k_sqrt_sweep<1>, dim3(n_cu * 8), dim3(256), 0, s, first, count, d_counts);
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }

@@ -24,16 +24,30 @@
 #define BL_SQRT_FAST_LO 0x1p-100f /* below: the residual is no longer exact (and v_sqrt flushes denormals) */
 #define BL_SQRT_FAST_HI 0x1p+126f
 
-/* s in [BL_SQRT_FAST_LO, BL_SQRT_FAST_HI] */
-__device__ __forceinline__ float bl_sqrt_rn_fast(float s) {
-  const float y = __builtin_amdgcn_sqrtf(s);
-  const float h = 0.5f * __builtin_amdgcn_rsqf(s);
-  const float r = __builtin_fmaf(-y, y, s);
-  return __builtin_fmaf(r, h, y);
+/* s in [BL_SQRT_FAST_LO, BL_SQRT_FAST_HI].  V = 1: v_sqrt + v_rsq + Markstein's final step;
+ * V = 2: v_rsq only, one coupled Newton step on (y, h) and the final step (Goldschmidt / IA-64
+ * form) — one transcendental instead of two, three more fmas. */
+template <int V> __device__ __forceinline__ float bl_sqrt_rn_fast(float s) {
+  if (V == 1) {
+    const float y = __builtin_amdgcn_sqrtf(s);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
+    const float r = __builtin_fmaf(-y, y, s);
+    return __builtin_fmaf(r, h, y);
+  }
+  const float q = __builtin_amdgcn_rsqf(s);
+  const float y0 = s * q, h0 = 0.5f * q;
+  const float e = __builtin_fmaf(-y0, h0, 0.5f);
+  const float y1 = __builtin_fmaf(y0, e, y0), h1 = __builtin_fmaf(h0, e, h0);
+  const float d = __builtin_fmaf(-y1, y1, s);
+  return __builtin_fmaf(d, h1, y1);
 }
 
-__device__ __forceinline__ bool bl_sqrt_fast_ok(float s) {
-  return s >= BL_SQRT_FAST_LO && s <= BL_SQRT_FAST_HI; /* false for NaN */
+/* in the domain <=> (bits - lo) <= (hi - lo) as unsigned integers: non-negative floats order like
+ * their bit patterns; zero, negative, infinite and NaN patterns all fall outside */
+__device__ __forceinline__ unsigned bl_sqrt_fast_key(float s) {
+  return __float_as_uint(s) - __float_as_uint(BL_SQRT_FAST_LO);
 }
+#define BL_SQRT_FAST_SPAN (0x7E800000u - 0x0D800000u) /* bits(2^126) - bits(2^-100) */
+__device__ __forceinline__ bool bl_sqrt_fast_ok(float s) { return bl_sqrt_fast_key(s) <= BL_SQRT_FAST_SPAN; }
 
 #endif /* BL_SQRT_H_ */
