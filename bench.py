@@ -455,7 +455,11 @@ def main():
             # counters of this kernel (SQ_INSTS_VALU / windows) x the windows of this launch / its
             # HIP-event time, against the f64 issue rate the chip sustains (tools/ubench_rate.hip)
             valu = None
-            if prof.get("valu_instr_per_window"):
+            prof_mode = prof.get("fir_mode") if prof.get("fir_mode") is not None else 0   # r02 profiles: mode 0
+            if prof.get("valu_instr_per_window") and prof_mode != fir_mode:
+                valu = {"frac": None, "error": f"committed profile {prof.get('file')} was taken in FIR mode {prof_mode}, "
+                                               f"this run is mode {fir_mode}: its instruction count does not apply"}
+            elif prof.get("valu_instr_per_window"):
                 rate = prof["valu_instr_per_window"] * windows / t_launch / 1e12
                 valu = {"achieved_Twaveinstr_per_s": rate, "peak_Twaveinstr_per_s": F64_ISSUE_TWAVEINSTR_S,
                         "frac": rate / F64_ISSUE_TWAVEINSTR_S,
