@@ -146,6 +146,22 @@ def test_distance_file_and_errors(gpu_lib, tmp_path):
     c = gpu_lib.bl_cosine_similarity_file(f, f, C.byref(s1), C.byref(s2))
     assert abs(c - 1.0) < 1e-6
     gpu_lib.bl_free_song(C.byref(s1)); gpu_lib.bl_free_song(C.byref(s2))
+    # two different files (ref src/analyze.c:105-125,145-167): the 22.05 kHz fixture and its 48 kHz /
+    # 24-bit sibling — both songs are filled, and the pair functions return exactly what the one-pair
+    # functions give on the two force vectors (and what the oracle gives on them)
+    g = os.path.join(HERE, "golden", "song_s32.flac").encode()
+    from tests.oracle_py import Oracle
+    orc = Oracle()
+    d = gpu_lib.bl_distance_file(f, g, C.byref(s1), C.byref(s2))
+    v1 = np.array([getattr(s1.force_vector, k) for k in ("tempo", "amplitude", "frequency", "attack")], dtype=np.float32)
+    v2 = np.array([getattr(s2.force_vector, k) for k in ("tempo", "amplitude", "frequency", "attack")], dtype=np.float32)
+    assert s1.nSamples == 488138 and s2.nSamples == 488140 and s2.resampled == 1
+    assert d > 0 and d == gpu_lib.bl_distance(s1.force_vector, s2.force_vector) == orc.distance(v1, v2)
+    assert abs(v2[0] - (-8.218182)) <= 1e-5 and abs(v1[0] - (-8.945454)) <= 1e-5      # the two goldens' tempi
+    gpu_lib.bl_free_song(C.byref(s1)); gpu_lib.bl_free_song(C.byref(s2))
+    c = gpu_lib.bl_cosine_similarity_file(g, f, C.byref(s1), C.byref(s2))
+    assert 0.99 < c < 1.0 and c == gpu_lib.bl_cosine_similarity(s1.force_vector, s2.force_vector) == orc.cosine(v2, v1)
+    gpu_lib.bl_free_song(C.byref(s1)); gpu_lib.bl_free_song(C.byref(s2))
     bad = str(tmp_path / "nope.flac").encode()
     assert gpu_lib.bl_analyze(bad, C.byref(s1)) == _lib.BL_UNEXPECTED
     assert gpu_lib.bl_distance_file(bad, f, C.byref(s1), C.byref(s2)) == float(_lib.BL_UNEXPECTED)

@@ -67,6 +67,55 @@ def make_song(seed, max_seconds, seconds=None, rate=None, channels=None):
     return pcm, ch, max(1, int(secs))
 
 
+_material = None
+
+
+def make_song_from_recording(seed, max_seconds, path):
+    """A song cut from real music instead of synthesised: random excerpts of the reference's own
+    recording (tests/golden/song.flac, 11 s of 22.05 kHz stereo, decoded by the library's FLAC
+    reader) looped / reversed / mixed at random gains, optionally down-mixed to mono, with the DC
+    offsets and silences of make_song.  Same spectrum and dynamics as the one real fixture the
+    reference has, in thousands of different alignments against the 256-sample window grid."""
+    global _material
+    if _material is None:
+        import ctypes as C
+        from bliss_amd import _lib
+        lib = _lib.load()
+        song = _lib.BlSong()
+        assert lib.bl_audio_decode(path.encode(), C.byref(song)) == _lib.BL_OK
+        _material = np.ctypeslib.as_array(C.cast(song.sample_array, C.POINTER(C.c_int16)),
+                                          shape=(song.nSamples,)).astype(np.float64).reshape(-1, 2).copy()
+        lib.bl_free_song(C.byref(song))
+    rng = np.random.default_rng(seed)
+    src = _material
+    ch = int(rng.integers(1, 3))
+    secs = float(rng.uniform(2.0, max_seconds))
+    frames = int(22050 * secs)
+    out = np.zeros((frames, 2))
+    for _ in range(int(rng.integers(1, 4))):                    # 1..3 layers
+        pos, gain = 0, 10 ** rng.uniform(-1.5, 0.2) * rng.choice([-1, 1])
+        while pos < frames:                                     # excerpts back to back
+            a = int(rng.integers(0, src.shape[0] - 4000))
+            ln = int(min(frames - pos, rng.integers(2000, src.shape[0] - a)))
+            piece = src[a:a + ln]
+            if rng.random() < 0.25:
+                piece = piece[::-1]
+            out[pos:pos + ln] += gain * piece
+            pos += ln
+    pcm = out.mean(axis=1) if ch == 1 else out.reshape(-1)
+    n = pcm.size + int(rng.integers(0, 7))
+    pcm = np.concatenate([pcm, rng.normal(0, 20.0, n - pcm.size)])
+    pcm += rng.choice([0, 0, 0, rng.uniform(-12000, 12000)])
+    pcm = np.clip(np.rint(pcm), -32768, 32767).astype(np.int16)
+    if rng.random() < 0.3:
+        pcm[: int(rng.integers(1, 3000))] = 0
+    if rng.random() < 0.3:
+        pcm[-int(rng.integers(1, 3000)):] = 0
+    if not pcm.any():
+        pcm[n // 2] = 1
+    return pcm, ch, max(1, int(secs))
+
+
 _orc = None
 
 
@@ -77,7 +126,10 @@ def _work(args):
         from oracle_py import Oracle
         _orc = Oracle()
     seed, kw = args
-    pcm, ch, dur = make_song(seed, **kw)
+    if kw.get("material"):
+        pcm, ch, dur = make_song_from_recording(seed, kw["max_seconds"], kw["material"])
+    else:
+        pcm, ch, dur = make_song(seed, **{k: v for k, v in kw.items() if k != "material"})
     return seed, pcm, ch, dur, _orc.analyze(pcm, ch, dur)
 
 
@@ -92,12 +144,14 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="songs per resident batch (0: sized for ~6 GB of PCM)")
     ap.add_argument("--fir-mode", type=int, default=-1, help="BL_AMD_FIR_FUSED for this run")
     ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--material", default="", help="cut the songs from this recording (FLAC / WAV, 22.05 kHz "
+                                                   "stereo) instead of synthesising them")
     a = ap.parse_args()
     if a.fir_mode >= 0:
         os.environ["BL_AMD_FIR_FUSED"] = str(a.fir_mode)
     import bliss_amd
     kw = dict(max_seconds=a.max_seconds, seconds=a.seconds or None, rate=a.rate or None,
-              channels=2 if a.stereo else None)
+              channels=2 if a.stereo else None, material=os.path.abspath(a.material) if a.material else None)
     seeds = [a.seed * 1000003 + i for i in range(a.songs)]
     est_bytes = 2 * 2 * (a.rate or 48000) * (a.seconds or a.max_seconds / 2)
     chunk = a.chunk or max(16, min(1024, int(6e9 / est_bytes)))
@@ -149,6 +203,8 @@ def main():
     print(json.dumps({"songs": a.songs, "seed": a.seed,
                       "shape": {"seconds": a.seconds or f"1..{a.max_seconds}", "rate": a.rate or "random",
                                 "channels": 2 if a.stereo else "random"},
+                      "material": (os.path.relpath(a.material, ROOT) + ": excerpts looped / reversed / mixed, 22.05 kHz")
+                      if a.material else "synthetic",
                       "fir_mode": os.environ.get("BL_AMD_FIR_FUSED", "default"),
                       "int_mismatches": bad_int[:10],
                       "n_int_mismatches": len(bad_int), "float_out_of_tolerance": bad_float[:10],
