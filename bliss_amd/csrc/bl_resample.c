@@ -195,9 +195,13 @@ static int32_t dot_s16_portable(const int16_t *src, const int16_t *filt, int all
 
 static int have_fma3(void) {
 #if defined(__x86_64__)
-  static int cached = -1;
-  if (cached < 0) cached = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
-  return cached;
+  static int cached = -1; /* every thread computes the same value: relaxed atomics are all it needs */
+  int c = __atomic_load_n(&cached, __ATOMIC_RELAXED);
+  if (c < 0) {
+    c = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    __atomic_store_n(&cached, c, __ATOMIC_RELAXED);
+  }
+  return c;
 #else
   return 0;
 #endif
