@@ -1215,7 +1215,8 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
           r[8 * u + 2 * k + 1] = nrm(hi - mean);
         }
       }
-      const double xh = nrm((int)preh - mean);
+      const int kh = (int)preh - mean;   /* this round's head sample: fetch() below overwrites preh */
+      const double xh = nrm(kh);
       fetch(rho + 1); /* next round's samples */
       /* 2. FIR (ref :123-138): outputs 16 ln .. 16 ln + 15 of the round's new samples */
 #pragma unroll
@@ -1229,7 +1230,6 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
        * costs half of a 64-bit one and folds into the add, and only the nine sums are converted —
        * 34 instead of 49 instructions, the same bits */
       if (FIR_MODE == 2) {
-        const int kh = (int)preh - mean;
 #define KH(m) __builtin_amdgcn_update_dpp(0, kh, 0x110 + (m), 0xF, 0xF, true) /* row_shr:m, 0 when there is no lane */
         const double p0 = (double)kh; /* tap 16 lies before the window: zero */
         const double p1 = (double)(KH(1) + KH(15)), p2 = (double)(KH(2) + KH(14)), p3 = (double)(KH(3) + KH(13));
