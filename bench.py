@@ -226,6 +226,8 @@ def self_launch(args, argv):
     if not args.plumbing_only:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if args.share_device and have >= 1:
+            have = args.gpus
         if have < args.gpus:
             print(f"bench.py --gpus {args.gpus}: this box exposes {have} HIP device(s); the N-GPU run needs "
                   f"{args.gpus} (one rank per GPU).  Nothing was launched.", file=sys.stderr)
@@ -308,6 +310,11 @@ def main():
                     help="diagnostic: size the gather buffer and this rank's row block as for a job of W ranks "
                          "(all_vecs = W x songs vectors, rows = songs x W*songs floats; the other ranks' vectors "
                          "are copies of this rank's) — checks that the configs[2] shard still fits at W = 8")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal of the N-rank job on ONE GPU: every rank uses device 0 and the process group is "
+                         "gloo (RCCL cannot put two ranks on one device), the vectors travel through host memory; "
+                         "everything else — shards, seeds, gather order, row blocks, the reductions — is the N-rank "
+                         "code.  Needs a small --songs-per-gpu; not a measurement")
     ap.add_argument("--launch", action="store_true",
                     help="start the ranks through the self-launcher even for --gpus 1 (RCCL group of one)")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -332,13 +339,20 @@ def main():
                          f"--nproc-per-node {args.gpus}, or run plain `python bench.py --gpus {args.gpus}` "
                          "(it launches its own ranks)")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.share_device:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but this box exposes "
                          f"{torch.cuda.device_count()} HIP device(s) (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # where the tensors of the collectives live: on the GPU for RCCL, in host memory for the gloo rehearsal
+    cdev = torch.device("cpu") if args.share_device else dev
     if world > 1 or (under_launcher and "MASTER_ADDR" in os.environ):  # torchrun: RCCL group even at world size 1
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import bliss_amd
     from bliss_amd import _lib
@@ -360,7 +374,7 @@ def main():
         songs = max(1, 1 << (max(fit, 1).bit_length() - 1))
         capped = True
     if dist.is_initialized():  # every rank uses the smallest count any rank can hold
-        t = torch.tensor([songs], device=dev)
+        t = torch.tensor([songs], device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         songs = int(t.item())
     from bliss_amd.dist import gather_force_vectors, shard_range
@@ -383,7 +397,7 @@ def main():
     def step():
         corpus.analyze()
         mine = corpus.force_vectors()
-        gathered = gather_force_vectors(mine, [songs] * world)        # RCCL all-gather, 16 B/song
+        gathered = gather_force_vectors(mine.to(cdev), [songs] * world).to(dev)   # RCCL all-gather, 16 B/song
         n_gathers[0] += 1
         if cols == total_songs:
             all_vecs.copy_(gathered)
@@ -411,7 +425,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.bl_amd_profile(0)
     if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -430,13 +444,27 @@ def main():
     ok = ok and bool(torch.equal(all_vecs[my_first:my_first + songs].cpu(),
                                  torch.from_numpy(np.stack([res[k] for k in ("tempo", "amplitude", "frequency",
                                                                              "attack")], axis=1))))
+    # every rank's row block holds bl_distance of its own songs against the gathered vectors: spot-check
+    # one entry per rank against the host form of the same expression (ref src/analyze.c:96-100)
+    if songs > 1 and cols >= 2:
+        i, j = songs - 1, (my_first + songs) % cols
+        a, b = all_vecs[my_first + i].cpu().numpy(), all_vecs[j].cpu().numpy()
+        want_d = lib.bl_distance(_lib.ForceVector(*[float(x) for x in a]), _lib.ForceVector(*[float(x) for x in b]))
+        ok = ok and float(rows[i, j].item()) == want_d
+    # the oracle check is shared out: every rank re-analyses its part of the --verify songs on the host
     verified, verify_details = 0, []
-    if rank == 0 and args.verify > 0:
-        k = min(args.verify, songs)
+    if args.verify > 0:
+        k = min(max(1, args.verify // world), songs)
         picks = sorted(set(int(round(j * (songs - 1) / max(k - 1, 1))) for j in range(k)))
         v_ok, verify_details = verify_songs(res, picks, my_first, args.seconds)
         ok = ok and v_ok
         verified = len(picks)
+    if dist.is_initialized():  # results_ok and verified_songs describe every rank, not only rank 0
+        t = torch.tensor([1 if ok else 0, verified], dtype=torch.int64, device=cdev)
+        tmin, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        ok, verified = bool(tmin[0].item()), int(tsum[1].item())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -539,12 +567,16 @@ def main():
             "whole_path_algorithmic_gbs_per_gpu": whole_path_gbs,
             "whole_path_frac_hbm": whole_path_gbs / HBM_PEAK_GBS,
             "kernels_ms": kern, "results_ok": ok, "verified_songs": verified,
-            "verification": {"against": "CPU oracle (oracle/orc_cli) on the re-synthesised songs, untimed",
+            "verification": {"against": "CPU oracle (oracle/orc_cli) on the re-synthesised songs, untimed; every rank "
+                                        "checks its share of --verify (results_ok / verified_songs are reduced over the "
+                                        "ranks, the list below is rank 0's)",
                              "bar": "integers identical, f32 features <= 1e-4 relative",
                              "songs": verify_details},
             "memory": {"free_bytes_before_alloc": int(free_b), "total_bytes": int(total_b),
                        "free_bytes_after_alloc": int(mem_after_alloc[0]),
                        "row_block_bytes": 4 * songs * cols, "emulated_world": args.emulate_world or None},
+            "rehearsal": ("ranks share device 0, gloo group, vectors staged through host memory: not a measurement"
+                          if args.share_device else None),
             "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                            "all_gather_calls": n_gathers[0] if dist.is_initialized() else 0,
                            "bytes_per_rank": 16 * songs},

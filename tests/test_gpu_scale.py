@@ -163,3 +163,21 @@ def test_fir_modes_agree(gpu_lib, oracle):
     finally:
         gpu_lib.bl_amd_set_fir_mode(-1)
     assert gpu_lib.bl_amd_set_fir_mode(3) == bliss_amd.BL_UNEXPECTED
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(gpu_lib):
+    """The N = 2 job of bench.py on a one-GPU box: --share-device puts both ranks on device 0 with a
+    gloo group (RCCL refuses two ranks per device).  Everything but the transport is the N-rank code:
+    the ranks' shards and seeds (rank 1 analyses songs 24..47), the gather order, row blocks that
+    start at row 24, the oracle check shared out over the ranks, results_ok reduced over both."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "1",
+           "--songs-per-gpu", "24", "--seconds", "20", "--no-cpu-baseline", "--verify", "8"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["results_ok"] is True and line["verified_songs"] == 8
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["all_gather_calls"] >= 2
+    assert line["config"]["songs_per_gpu"] == 24 and line["config"]["parallelism"] == "shard2"
+    assert "48 songs total" in line["config"]["workload"] and line["rehearsal"]

@@ -76,6 +76,27 @@ template <int ROWS> __global__ __launch_bounds__(256) void k_rowgroup_rowmajor(f
     }
 }
 
+// persistent form of the pairwise tile: WGs loop over (row group, column tile) tiles with a grid stride
+template <int ROWS> __global__ __launch_bounds__(256) void k_tiles_persistent(float *out, int n, float v) {
+  const int ct = (n + 1023) / 1024, rt = (n + ROWS - 1) / ROWS;
+  for (int t = blockIdx.x; t < ct * rt; t += gridDim.x) {
+    const int c0 = (t % ct) * 1024, r0 = (t / ct) * ROWS;
+    const int j = c0 + threadIdx.x * 4;
+    for (int row = r0; row < r0 + ROWS && row < n; ++row)
+      if (j + 4 <= n) *reinterpret_cast<float4 *>(out + (size_t)row * n + j) = make_float4(v, v + row, v, v);
+  }
+}
+// column-tile-major order of the same tiles (a WG's successive tiles walk DOWN a column strip)
+template <int ROWS> __global__ __launch_bounds__(256) void k_tiles_colmajor(float *out, int n, float v) {
+  const int ct = (n + 1023) / 1024, rt = (n + ROWS - 1) / ROWS;
+  for (int t = blockIdx.x; t < ct * rt; t += gridDim.x) {
+    const int c0 = (t / rt) * 1024, r0 = (t % rt) * ROWS;
+    const int j = c0 + threadIdx.x * 4;
+    for (int row = r0; row < r0 + ROWS && row < n; ++row)
+      if (j + 4 <= n) *reinterpret_cast<float4 *>(out + (size_t)row * n + j) = make_float4(v, v + row, v, v);
+  }
+}
+
 template <typename F> float timeit(F f) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 3; ++i) f();
@@ -120,6 +141,20 @@ int main() {
   rep("row group 16, rows outer", timeit([&] { hipLaunchKernelGGL(k_rowgroup_rowmajor<16>, dim3((n + 15) / 16), dim3(256), 0, 0, out, n, 1.f); }));
   rep("row group 4, rows outer", timeit([&] { hipLaunchKernelGGL(k_rowgroup_rowmajor<4>, dim3((n + 3) / 4), dim3(256), 0, 0, out, n, 1.f); }));
   rep("row group 1, rows outer", timeit([&] { hipLaunchKernelGGL(k_rowgroup_rowmajor<1>, dim3(n), dim3(256), 0, 0, out, n, 1.f); }));
+  for (int wgs : {1024, 1536, 2048, 3072, 4096}) {
+    char nm[80];
+    snprintf(nm, sizeof nm, "persistent 16x1024 tiles, %d WGs", wgs);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(k_tiles_persistent<16>, dim3(wgs), dim3(256), 0, 0, out, n, 1.f); }));
+    snprintf(nm, sizeof nm, "persistent 8x1024 tiles, %d WGs", wgs);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(k_tiles_persistent<8>, dim3(wgs), dim3(256), 0, 0, out, n, 1.f); }));
+    snprintf(nm, sizeof nm, "persistent 16x1024 tiles col-major, %d WGs", wgs);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(k_tiles_colmajor<16>, dim3(wgs), dim3(256), 0, 0, out, n, 1.f); }));
+  }
+  for (size_t kb : {128, 200, 256, 320, 400}) {
+    const size_t chunk4 = kb * 1024 / 16;
+    char nm[64]; snprintf(nm, sizeof nm, "chunked linear, %zu KB per WG", kb);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(k_chunk, dim3((unsigned)((n4 + chunk4 - 1) / chunk4)), dim3(256), 0, 0, (float4 *)out, n4, chunk4, 1.f); }));
+  }
   hipFree(out);
   return 0;
 }
