@@ -89,3 +89,14 @@ def test_scalar_helpers_are_the_reference_expressions(lib, oracle):
 def test_return_codes():
     assert (bliss_amd.BL_LOUD, bliss_amd.BL_CALM, bliss_amd.BL_UNKNOWN,
             bliss_amd.BL_UNEXPECTED, bliss_amd.BL_OK) == (0, 1, 2, -2, 0)
+
+
+def test_headers_compile_as_c99_without_hip():
+    """include/bliss.h and include/bliss_amd.h are plain C: the resident-corpus caller of
+    INTEGRATION.md section 4 compiles with gcc -std=c99 and nothing but the two headers."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for src in ("multi_device_caller.c", "dropin_check.c"):
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
+                        "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", src)], check=True)
