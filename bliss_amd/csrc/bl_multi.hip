@@ -383,8 +383,6 @@ int bl_amd_analyze_corpus_multi_device(const bl_amd_shard *shards, int n_shards,
     f += shards[r].n_songs;
     m = std::max(m, shards[r].n_songs);
   }
-  bool any_rows = h_matrix != nullptr;
-  for (int r = 0; r < W; ++r) any_rows = any_rows || shards[r].d_rows;
   for (int r = 0; r < W; ++r) rows[r] = (h_matrix || shards[r].d_rows) ? shards[r].n_songs : 0;
   std::vector<int32_t> order((size_t)W * m, -1);
   for (int r = 0; r < W; ++r)
@@ -400,7 +398,6 @@ int bl_amd_analyze_corpus_multi_device(const bl_amd_shard *shards, int n_shards,
     threads.emplace_back(rank_main_device, &call, r, g_multi.ctx[r], comms[r], &shards[r],
                          h_results ? h_results + first[r] : nullptr);
   for (auto &t : threads) t.join();
-  (void)any_rows;
   return failed.load() ? BL_UNEXPECTED : BL_OK;
 }
 
