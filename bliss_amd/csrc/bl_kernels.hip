@@ -1144,7 +1144,9 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
   /* mode 2 filters the integers k = s - mean themselves (the taps carry the division) */
   auto nrm = [&](int k) -> double { return FIR_MODE == 2 ? (double)k : bl_norm(k, rcp, rcp_lo); };
   const int r0 = run_begin(u0 + wave), r1 = run_begin(u0 + wave + 1);
-  constexpr int EV3_W1_REGS = 13; /* pass-1 twiddles 1..12 in registers, 13..15 from LDS */
+  /* pass-1 twiddles kept in registers, the rest read from LDS in the round: modes 0 / 1 have room for 12
+   * (221 VGPRs); mode 2 needs fewer registers for the FIR and takes all 15 (232 VGPRs, no spill; 1 % faster) */
+  constexpr int EV3_W1_REGS = FIR_MODE == 2 ? 16 : 13;
   c2d w1r[EV3_W1_REGS];
 #pragma unroll
   for (int k1 = 1; k1 < EV3_W1_REGS; ++k1) {
