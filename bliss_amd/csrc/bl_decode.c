@@ -754,11 +754,13 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
       song->sample_array = (int8_t *)sink.p16;
       sink.p16 = NULL;
     }
-    /* ref src/decode.c:191-193: the reference reports two channels whatever the file has.  A mono
-     * S16 file at 22 050 Hz is the one case in which that is not true of its samples (no
-     * converter ran): the reference's analyzers then read them as interleaved pairs, and so do
-     * ours — same numbers, which is what a drop-in owes. */
-    song->channels = 2;
+    /* ref src/decode.c:191-193 reports two channels whatever the file has — true of everything that
+     * went through the converter (stereo output layout).  The one case it is not true of is a MONO
+     * S16 file at 22 050 Hz: no converter runs, and the reference's append_buffer_to_song() copies
+     * 2 x nb_samples x 2 bytes out of a frame that holds half of that (ref :353-354,368-370) — it reads
+     * past the decoder's buffer, so there is no defined reference result to reproduce.  Such a file
+     * keeps channels = 1 here and goes through the analyzers' mono branch. */
+    if (sink.non_s16 || song->channels == 2) song->channels = 2;
   }
   sink_free(&sink);
   if (rc != BL_OK) {
