@@ -8,13 +8,13 @@ from . import _lib
 from ._lib import (BL_CALM, BL_LOUD, BL_OK, BL_UNEXPECTED, BL_UNKNOWN, BlSong, EnvelopeResult,
                    ForceVector, SongDesc, SongResult, load)
 from . import distance, version
-from .batch import (Context, DeviceCorpus, analyze_batch_host, analyze_batch_host_rate, analyze_batch_host_s32,
+from .batch import (Context, DeviceCorpus, analyze_batch_host, analyze_files, analyze_batch_host_rate, analyze_batch_host_s32,
                     analyze_corpus_multi, analyze_corpus_multi_device, cosine_matrix, distance_matrix, playlist, resample_batch_device,
                     resample_host, results_to_numpy)
 from .bl_song import bl_song
 
 __all__ = ["_lib", "load", "BlSong", "ForceVector", "EnvelopeResult", "SongDesc", "SongResult",
            "BL_LOUD", "BL_CALM", "BL_UNKNOWN", "BL_UNEXPECTED", "BL_OK", "DeviceCorpus",
-           "analyze_batch_host", "analyze_batch_host_rate", "analyze_batch_host_s32", "analyze_corpus_multi", "analyze_corpus_multi_device", "Context",
+           "analyze_batch_host", "analyze_files", "analyze_batch_host_rate", "analyze_batch_host_s32", "analyze_corpus_multi", "analyze_corpus_multi_device", "Context",
            "distance_matrix", "cosine_matrix", "results_to_numpy", "playlist",
            "resample_host", "resample_batch_device", "bl_song", "distance", "version"]

@@ -89,6 +89,7 @@ SYMBOLS = {
                                                   C.c_void_p]),
     "bl_amd_ctx_analyze_batch_host": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
                                                 _P(C.c_uint64), C.c_int, _P(SongResult)]),
+    "bl_amd_analyze_files": (C.c_int, [_P(C.c_char_p), C.c_int, _P(BlSong), _P(C.c_int), C.c_int, C.c_int]),
     "bl_amd_set_host_transfer": (C.c_int, [C.c_int]),
     "bl_amd_analyze_batch_host_s32": (C.c_int, [_P(C.c_void_p), _P(C.c_int32), _P(C.c_int32),
                                                 _P(C.c_uint64), C.c_int, _P(SongResult)]),

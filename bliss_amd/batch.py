@@ -1,6 +1,7 @@
 """Batch helpers over the C-ABI: device-resident corpora (torch owns the memory,
 the library owns the arithmetic) and host-pointer conveniences."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -156,6 +157,40 @@ def analyze_batch_host(pcm_list, channels, durations):
     args, out, _keep = _host_args(pcm_list, channels, durations, np.int16)
     _check(lib.bl_amd_analyze_batch_host(*args, out), "bl_amd_analyze_batch_host")
     return results_to_numpy(bytes(out))
+
+
+def analyze_files(filenames, n_threads=0, keep_pcm=False):
+    """`for f in filenames: bl_analyze(f)` as one call (bl_amd_analyze_files): files decoded on host
+    threads while earlier ones are transferred and analysed.  Returns (list of dicts with the
+    song's fields, or None where the file could not be analysed; array of bl_analyze codes)."""
+    lib = _lib.load()
+    n = len(filenames)
+    names = (C.c_char_p * n)(*[os.fsencode(f) for f in filenames])
+    songs = (_lib.BlSong * n)()
+    codes = (C.c_int * n)()
+    got = lib.bl_amd_analyze_files(names, n, songs, codes, int(n_threads), int(bool(keep_pcm)))
+    if got == _lib.BL_UNEXPECTED:
+        for sg in songs:
+            lib.bl_free_song(C.byref(sg))
+        raise RuntimeError("bl_amd_analyze_files failed with BL_UNEXPECTED; see stderr")
+    out = []
+    for i in range(n):
+        sg = songs[i]
+        if codes[i] == _lib.BL_UNEXPECTED:
+            out.append(None)
+        else:
+            rec = {k: getattr(sg, k) for k in ("force", "channels", "nSamples", "sample_rate", "bitrate",
+                                                 "nb_bytes_per_sample", "calm_or_loud", "resampled", "duration")}
+            rec["force_vector"] = {k: getattr(sg.force_vector, k) for k in ("tempo", "amplitude", "frequency", "attack")}
+            for k in ("filename", "artist", "title", "album", "tracknumber", "genre"):
+                v = getattr(sg, k)
+                rec[k] = v.decode("utf-8", "replace") if v is not None else None
+            if keep_pcm and sg.sample_array:
+                rec["pcm"] = np.ctypeslib.as_array(C.cast(sg.sample_array, C.POINTER(C.c_int16)),
+                                                   shape=(sg.nSamples,)).copy()
+            out.append(rec)
+        lib.bl_free_song(C.byref(sg))
+    return out, np.array(list(codes), dtype=np.int32)
 
 
 def analyze_batch_host_s32(pcm_list, channels, durations):

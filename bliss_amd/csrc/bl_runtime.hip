@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <thread>
 
 #include "bl_runtime.h"
@@ -904,6 +905,124 @@ int bl_amd_analyze_batch_host(const int16_t *const *h_pcm, const int32_t *n_samp
                               bl_amd_song_result *h_results) {
   return bl_amd_ctx_analyze_batch_host(blr_default_ctx(), h_pcm, n_samples, channels, duration, n_songs,
                                        h_results);
+}
+
+/* The corpus loop of ref python/examples/make_m3u_playlist.py:51-72 / examples/analyze.c:17 as one
+ * call: `for file: bl_analyze(file, &song)`.  Decoding (bl_audio_decode: FLAC / WAV readers, rate
+ * converter) runs on n_threads host threads that stay a bounded number of files ahead; the calling
+ * thread takes the decoded songs in file order, wave by wave, through the pinned-staging host path
+ * (blr_analyze_host), so that the next wave is being decoded while this one is transferred and
+ * analysed.  Every songs[i] ends up exactly as bl_analyze(filenames[i], &songs[i]) leaves it. */
+int bl_amd_analyze_files(const char *const *filenames, int n_files, struct bl_song *songs, int *codes,
+                         int n_threads, int keep_pcm) {
+  if (n_files <= 0 || !filenames || !songs) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+  n_threads = std::min(n_threads, n_files);
+  const size_t WAVE_BYTES = (size_t)1 << 30; /* decoded PCM per wave */
+  const int WAVE_FILES = 512, AHEAD_FILES = 768; /* AHEAD_FILES >= WAVE_FILES: a wave never waits for a file the decoders may not take */
+
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<signed char> state((size_t)n_files, 0); /* 0 pending, 1 decoded, -1 failed */
+  int next = 0, limit = std::min(n_files, AHEAD_FILES); /* decoders take indices below `limit` */
+  bool stop = false;
+  auto decoder = [&] {
+    for (;;) {
+      int i;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || next < limit; });
+        if (stop || next >= n_files) return;
+        i = next++;
+      }
+      const int rc = filenames[i] ? bl_audio_decode(filenames[i], &songs[i]) : BL_UNEXPECTED;
+      if (rc != BL_OK) fprintf(stderr, "Couldn't decode song\n"); /* ref src/analyze.c:83 */
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        state[(size_t)i] = rc == BL_OK ? 1 : -1;
+      }
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n_threads; ++t) pool.emplace_back(decoder);
+
+  int done = 0, ok_count = 0, rc_all = BL_OK;
+  std::vector<const void *> pcm;
+  std::vector<int32_t> ns, ch;
+  std::vector<uint64_t> du;
+  std::vector<int> idx;
+  std::vector<bl_amd_song_result> res;
+  while (done < n_files) {
+    /* the next wave: files in order until the byte or file budget is reached; wait for each decode */
+    pcm.clear(); ns.clear(); ch.clear(); du.clear(); idx.clear();
+    size_t bytes = 0;
+    int e = done;
+    while (e < n_files && (int)(e - done) < WAVE_FILES && bytes < WAVE_BYTES) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return state[(size_t)e] != 0; });
+      }
+      if (codes) codes[e] = BL_UNEXPECTED;
+      if (state[(size_t)e] == 1) {
+        const struct bl_song &sg = songs[e];
+        /* what run_song() of bl_api.c and validate_desc() accept; anything else is reported per file */
+        if (sg.sample_array && sg.nSamples >= 5120 && (sg.channels == 1 || sg.channels == 2) && sg.duration > 0) {
+          pcm.push_back(sg.sample_array); ns.push_back(sg.nSamples); ch.push_back(sg.channels);
+          du.push_back(sg.duration); idx.push_back(e);
+          bytes += (size_t)sg.nSamples * 2;
+        } else {
+          fprintf(stderr, "bliss_amd: %s not analysable (need >= 5120 s16 samples, 1 or 2 channels, >= 1 s)\n",
+                  filenames[e]);
+        }
+      }
+      ++e;
+    }
+    { /* let the decoders run ahead of the wave that is about to be analysed */
+      std::lock_guard<std::mutex> lk(mu);
+      limit = std::min(n_files, e + AHEAD_FILES);
+    }
+    cv.notify_all();
+    if (!idx.empty()) {
+      res.assign(idx.size(), bl_amd_song_result());
+      int rc;
+      {
+        std::lock_guard<std::mutex> lk(c->mu);
+        DevGuard dg(c->device);
+        rc = dg.ok ? blr_analyze_host(c, pcm.data(), 0, ns.data(), ch.data(), du.data(), (int)idx.size(), 0,
+                                      res.data(), nullptr)
+                   : BL_UNEXPECTED;
+      }
+      if (rc != BL_OK) rc_all = BL_UNEXPECTED;
+      for (size_t k = 0; k < idx.size(); ++k) {
+        struct bl_song &sg = songs[idx[k]];
+        if (rc == BL_OK && res[k].status == BL_OK) {
+          sg.force_vector = res[k].v;            /* ref src/analyze.c:63-66 */
+          sg.force = res[k].force;               /* ref :68-72 */
+          sg.calm_or_loud = res[k].calm_or_loud; /* ref :73-79 */
+          if (codes) codes[idx[k]] = res[k].calm_or_loud;
+          ++ok_count;
+        } else {
+          fprintf(stderr, "Couldn't analyse song on the HIP device\n");
+        }
+      }
+    }
+    if (!keep_pcm)
+      for (int i = done; i < e; ++i) {
+        free(songs[i].sample_array);
+        songs[i].sample_array = NULL;
+      }
+    done = e;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = true;
+  }
+  cv.notify_all();
+  for (auto &t : pool) t.join();
+  return rc_all == BL_OK ? ok_count : BL_UNEXPECTED;
 }
 
 int bl_amd_analyze_batch_host_s32(const int32_t *const *h_pcm, const int32_t *n_samples,

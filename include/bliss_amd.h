@@ -93,6 +93,20 @@ int bl_amd_ctx_analyze_batch_host(bl_amd_ctx *ctx, const int16_t *const *h_pcm,
                                   const int32_t *n_samples, const int32_t *channels,
                                   const uint64_t *duration, int n_songs,
                                   bl_amd_song_result *h_results);
+/* The reference's corpus loop — `for file: bl_analyze(file, &song)` (ref python/examples/
+ * make_m3u_playlist.py:51-72, examples/analyze.c:17) — as one call.  Files are decoded
+ * (bl_audio_decode) on n_threads host threads (0 = one per hardware thread, at most 32) that run a
+ * bounded number of files ahead; the decoded songs go to the GPU in file order, wave by wave,
+ * through the pinned-staging path of bl_amd_analyze_batch_host, so decoding, transfer and
+ * analysis overlap.  songs[i] (caller-owned, uninitialised is fine) is filled exactly as
+ * bl_analyze(filenames[i], &songs[i]) fills it — release each with bl_free_song; with
+ * keep_pcm == 0 the sample_array is freed (and NULL) once the song has been analysed.
+ * codes (optional, n_files ints) receives what bl_analyze would have returned for the file:
+ * BL_LOUD / BL_CALM / BL_UNKNOWN or BL_UNEXPECTED.  Returns the number of files analysed, or
+ * BL_UNEXPECTED if the device path itself failed.  Blocking. */
+int bl_amd_analyze_files(const char *const *filenames, int n_files, struct bl_song *songs, int *codes,
+                         int n_threads, int keep_pcm);
+
 /* How host buffers reach the device: BL_AMD_HOST_STAGED copies them into the library's pinned
  * double buffers on several host threads (default); BL_AMD_HOST_REGISTERED pins the caller's
  * buffers in place with hipHostRegister for the duration of the call (free() stays valid,

@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 import bliss_amd
 from bliss_amd import _lib
 
@@ -65,6 +67,18 @@ def test_no_device_fails_loudly(lib):
         bliss_amd.analyze_batch_host([pcm], 1, 1)
     ctx = C.c_void_p()
     assert lib.bl_amd_ctx_create(0, C.byref(ctx)) == _lib.BL_UNEXPECTED and not ctx.value
+
+
+def test_analyze_files_fails_loudly_without_a_device(lib, tmp_path):
+    """The file-batch call has no CPU path either: without a HIP device it returns BL_UNEXPECTED."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    names = (C.c_char_p * 1)(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "song.flac").encode())
+    songs = (_lib.BlSong * 1)()
+    codes = (C.c_int * 1)()
+    assert lib.bl_amd_analyze_files(names, 1, songs, codes, 1, 0) == _lib.BL_UNEXPECTED
+    assert lib.bl_amd_analyze_files(None, 1, songs, codes, 1, 0) == _lib.BL_UNEXPECTED
 
 
 def test_scalar_helpers_are_the_reference_expressions(lib, oracle):

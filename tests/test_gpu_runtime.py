@@ -264,3 +264,54 @@ def test_scalar_helpers_match_the_kernels(gpu_lib):
         a, b = _lib.ForceVector(*v[i]), _lib.ForceVector(*v[j])
         assert gpu_lib.bl_distance(a, b) == dm[i, j]
         assert gpu_lib.bl_cosine_similarity(a, b) == cm[i, j]
+
+
+def test_analyze_files_equals_the_per_file_loop(gpu_lib, oracle, tmp_path):
+    """bl_amd_analyze_files(filenames, ...) is `for f: bl_analyze(f, &song)` with the decoding on host
+    threads and the songs batched to the GPU: every song struct — force vector, force, calm_or_loud,
+    metadata — equals what the one-file call gives, bit for bit; a missing file and a clip that is
+    too short are reported per file and do not stop the rest."""
+    import shutil
+    from tests.test_ingest import write_flac_verbatim, _write_wav16
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    files = []
+    for name in ("song.flac", "song_s32.flac", "song_s32_mono.flac"):
+        dst = tmp_path / name
+        shutil.copy(os.path.join(gold, name), dst)
+        files.append(str(dst))
+    for i in range(9):
+        rate, ch, secs = (22050, 44100, 48000)[i % 3], 1 + (i % 2), 5 + i % 5   # the test FLAC writer stops at 128 frames of 4096
+        pcm = oracle.synth(6100 + i, rate, ch, rate * ch * secs)
+        f = tmp_path / f"synth{i}.{'flac' if i % 2 else 'wav'}"
+        if i % 2:
+            write_flac_verbatim(f, pcm, ch, rate, 16)
+        else:
+            _write_wav16(f, pcm, ch, rate)
+        files.append(str(f))
+    missing = str(tmp_path / "missing.flac")
+    short = tmp_path / "short.wav"
+    _write_wav16(short, oracle.synth(1, 22050, 2, 3000), 2, 22050)
+    order = files[:5] + [missing] + files[5:9] + [str(short)] + files[9:]
+    recs, codes = bliss_amd.analyze_files(order, n_threads=4)
+    assert len(recs) == len(order) == 14
+    n_ok = 0
+    for f, rec, code in zip(order, recs, codes):
+        song = _lib.BlSong()
+        rc = gpu_lib.bl_analyze(f.encode(), C.byref(song))
+        assert rc == code, f
+        if rc == _lib.BL_UNEXPECTED:
+            assert rec is None and f in (missing, str(short))
+            gpu_lib.bl_free_song(C.byref(song))   # bl_analyze leaves a decoded-but-unanalysable song allocated
+            continue
+        n_ok += 1
+        for k in ("tempo", "amplitude", "frequency", "attack"):
+            assert rec["force_vector"][k] == getattr(song.force_vector, k), (f, k)
+        assert rec["force"] == song.force and rec["calm_or_loud"] == song.calm_or_loud
+        for k in ("channels", "nSamples", "sample_rate", "bitrate", "nb_bytes_per_sample", "resampled", "duration"):
+            assert rec[k] == getattr(song, k), (f, k)
+        assert rec["title"] == song.title.decode() and rec["filename"] == f
+        gpu_lib.bl_free_song(C.byref(song))
+    assert n_ok == 12
+    # keep_pcm: the decoded samples stay with the song
+    recs2, _ = bliss_amd.analyze_files(order[:2], n_threads=1, keep_pcm=True)
+    assert recs2[0]["pcm"].size == recs2[0]["nSamples"] == 488138
