@@ -17,6 +17,11 @@
 #ifndef BL_BLISS_H_
 #define BL_BLISS_H_
 
+/* what callers of the reference header get transitively from libavformat's headers and use
+ * without including it themselves (ref examples/analyze.c:40 PRId64, examples/detect-gapless.c:28,38
+ * PRId16 / fabs): kept, so that such sources compile unchanged */
+#include <inttypes.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

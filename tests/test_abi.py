@@ -111,6 +111,6 @@ def test_headers_compile_as_c99_without_hip():
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for src in ("multi_device_caller.c", "dropin_check.c"):
+    for src in ("multi_device_caller.c", "dropin_check.c", "caller_relying_on_transitive_headers.c"):
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
                         "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", src)], check=True)
