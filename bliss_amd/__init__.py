@@ -18,3 +18,11 @@ __all__ = ["_lib", "load", "BlSong", "ForceVector", "EnvelopeResult", "SongDesc"
            "analyze_batch_host", "analyze_files", "analyze_batch_host_rate", "analyze_batch_host_s32", "analyze_corpus_multi", "analyze_corpus_multi_device", "Context",
            "distance_matrix", "cosine_matrix", "results_to_numpy", "playlist",
            "resample_host", "resample_batch_device", "bl_song", "distance", "version"]
+
+
+def __getattr__(name):
+    """`bliss_amd.lib`: the loaded C library, the counterpart of the reference's `bliss.lib`
+    (ref python/bliss/__init__.py:5) — e.g. `bliss_amd.lib.bl_version()`.  Loaded on first use."""
+    if name == "lib":
+        return load()
+    raise AttributeError(f"module 'bliss_amd' has no attribute {name!r}")

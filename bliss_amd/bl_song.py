@@ -117,3 +117,23 @@ class bl_song(Mapping):
             del self._keepalive[k]
             setattr(self._c_struct, k, None)
         self._lib.bl_free_song(C.byref(self._c_struct))
+
+
+def distance(filename1, filename2):
+    """ref python/bliss/bl_song.py:212-231: bl_distance_file on two files; returns
+    {distance, song1, song2} with the two analysed songs."""
+    lib = _lib.load()
+    s1, s2 = _lib.BlSong(), _lib.BlSong()
+    value = lib.bl_distance_file(filename1.encode("utf-8"), filename2.encode("utf-8"), C.byref(s1), C.byref(s2))
+    return {"distance": value, "song1": bl_song(c_struct=s1), "song2": bl_song(c_struct=s2)}
+
+
+def cosine_similarity(filename1, filename2):
+    """ref python/bliss/bl_song.py:234-254.  The reference's wrapper passes four arguments to the
+    two-argument bl_cosine_similarity (SURVEY.md section 8b notes the latent bug); the call it
+    means is bl_cosine_similarity_file, which is what runs here."""
+    lib = _lib.load()
+    s1, s2 = _lib.BlSong(), _lib.BlSong()
+    value = lib.bl_cosine_similarity_file(filename1.encode("utf-8"), filename2.encode("utf-8"), C.byref(s1),
+                                          C.byref(s2))
+    return {"similarity": value, "song1": bl_song(c_struct=s1), "song2": bl_song(c_struct=s2)}

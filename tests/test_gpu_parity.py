@@ -330,6 +330,17 @@ def test_python_surface_mirrors_reference(gpu_lib):
     d["song1"].free(); d["song2"].free()
     assert bliss_amd.distance.distance(1, 2) == {"distance": None, "song1": None, "song2": None}
     assert abs(bliss_amd.version.version() - 1.2) < 1e-6
+    # module-level wrappers of ref python/bliss/bl_song.py:212-254 and `bliss.lib`
+    import importlib
+    bl_song_module = importlib.import_module("bliss_amd.bl_song")   # the package attribute is the class, as in the reference
+    g = os.path.join(HERE, "golden", "song_s32.flac")
+    d = bl_song_module.distance(f, g)
+    c = bl_song_module.cosine_similarity(f, g)
+    assert d["distance"] > 0 and d["distance"] == bliss_amd.distance.distance(d["song1"], d["song2"])["distance"]
+    assert 0.99 < c["similarity"] < 1.0 and c["song2"]["resampled"] == 1
+    for r in (d, c):
+        r["song1"].free(); r["song2"].free()
+    assert bliss_amd.lib.bl_version() == bliss_amd.load().bl_version()
 
 
 def test_extreme_amplitudes(gpu_lib, oracle):
