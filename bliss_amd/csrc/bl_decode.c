@@ -59,6 +59,8 @@ static int native_rate_allowed(void) {
   const char *e = getenv("BL_AMD_ALLOW_NATIVE_RATE"); /* not cached: getenv is cheap next to a decode */
   return e && *e && strcmp(e, "0") != 0;
 }
+/* read ONCE per decode (bl_audio_decode stores the answer in the sink): the setter may run while a
+ * decode is in flight, and a sink filled as wide must not meet a branch that expects narrowed samples */
 
 /* a sample of `bps` significant bits as the s16 the analyzers read: left-justify in 32 bits,
  * arithmetic >> 16 */
@@ -79,6 +81,7 @@ typedef struct {
   int non_s16;  /* the source's sample format is not S16 for FFmpeg (u8, 24 / 32 bit, float): the
                  * reference sends such a file through libswresample even at 22 050 Hz */
   uint32_t bps; /* significant bits of the source */
+  int native;   /* native_rate_allowed() as this decode saw it when it started */
 } pcm_sink;
 
 static int sink_reserve(pcm_sink *s, size_t more) {
@@ -109,11 +112,11 @@ static void sink_free(pcm_sink *s) {
   s->p32 = NULL;
 }
 
-static int wants_rate_conversion(uint32_t rate);
+static int wants_rate_conversion(uint32_t rate, int native);
 /* keep all 32 bits: the source is wider than 16 bits and a float stage follows — the rate
  * converter, or the mono up-mix of a same-rate file (bl_audio_decode) */
-static int wants_wide(uint32_t bits, uint32_t rate, uint32_t channels) {
-  return bits > 16 && (wants_rate_conversion(rate) || (channels == 1 && !native_rate_allowed()));
+static int wants_wide(uint32_t bits, uint32_t rate, uint32_t channels, int native) {
+  return bits > 16 && (wants_rate_conversion(rate, native) || (channels == 1 && !native));
 }
 
 /* ----------------------------------------------------------------------- */
@@ -232,7 +235,7 @@ static int decode_wav(const uint8_t *d, size_t len, struct bl_song *song, pcm_si
       if (n == 0) return BL_UNEXPECTED;
       /* 8-bit PCM is unsigned; as s16 it is (v - 128) << 8, the conversion every 16-bit path starts from */
       sink->bps = bits == 8 ? 16 : bits;
-      sink->wide = wants_wide(bits, rate, channels);
+      sink->wide = wants_wide(bits, rate, channels, sink->native);
       sink->is_float = is_float && sink->wide;
       sink->non_s16 = bits != 16;
       if (sink_reserve(sink, n)) return BL_UNEXPECTED;
@@ -543,7 +546,7 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
   size_t audio_start = pos;
 
   sink->bps = fi.bps;
-  sink->wide = wants_wide(fi.bps, fi.rate, fi.channels);
+  sink->wide = wants_wide(fi.bps, fi.rate, fi.channels, sink->native);
   sink->non_s16 = fi.bps > 16; /* FFmpeg's FLAC decoder delivers S16 up to 16 bits, S32 above */
   if (sink_reserve(sink, fi.total ? (size_t)fi.total * fi.channels / 2 + 8 : (size_t)1 << 19))
     return BL_UNEXPECTED;
@@ -658,8 +661,8 @@ static int decode_flac(const uint8_t *d, size_t len, struct bl_song *song, pcm_s
   return BL_OK;
 }
 
-static int wants_rate_conversion(uint32_t rate) {
-  return rate != BL_DECODE_RATE && !native_rate_allowed();
+static int wants_rate_conversion(uint32_t rate, int native) {
+  return rate != BL_DECODE_RATE && !native;
 }
 
 /* ref include/bliss.h:234-235 / src/decode.c:27-213 */
@@ -682,11 +685,12 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
   int rc = BL_UNEXPECTED;
   pcm_sink sink;
   memset(&sink, 0, sizeof sink);
+  sink.native = native_rate_allowed();
   if (len >= 4 && !memcmp(data, "fLaC", 4)) rc = decode_flac(data, len, song, &sink, NULL);
   else if (len >= 12 && !memcmp(data, "RIFF", 4)) rc = decode_wav(data, len, song, &sink);
   else fprintf(stderr, "Unsupported container (WAV integer PCM / FLAC only): %s\n", filename);
   free(data);
-  if (rc == BL_OK && wants_rate_conversion((uint32_t)song->sample_rate)) {
+  if (rc == BL_OK && wants_rate_conversion((uint32_t)song->sample_rate, sink.native)) {
     /* ref src/decode.c:317-346: anything that is not 22 050 Hz s16 goes through the rate
      * converter and comes out as 22 050 Hz stereo s16 */
     int16_t *out = NULL;
@@ -710,7 +714,7 @@ int bl_audio_decode(char const *const filename, struct bl_song *const song) {
       song->sample_rate = BL_DECODE_RATE;
       song->resampled = 1;
     }
-  } else if (rc == BL_OK && native_rate_allowed()) { /* the caller's own business: as decoded */
+  } else if (rc == BL_OK && sink.native) { /* the caller's own business: as decoded */
     song->sample_array = (int8_t *)sink.p16;
     sink.p16 = NULL;
   } else if (rc == BL_OK) {

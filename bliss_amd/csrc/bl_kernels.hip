@@ -18,8 +18,6 @@
  *   k_freq_finish  dB spectrum, 5 bands, score  ref src/frequency_sort.c:97-139
  *   k_env_windows3 normalise, 17-tap FIR, 512-pt f64 real DFT, f32-rounded
  *                  energy per window            ref src/tempo_atk_sort.c:109-153
- *                  (k_env_windows2: the round-robin predecessor, kept as the
- *                  probe instantiation and for BL_AMD_ENV_OLD=1 comparisons)
  *   k_env_tail     IIR, box filters, peaks, tempo/attack
  *                                               ref src/tempo_atk_sort.c:184-284
  *   k_force        force, calm_or_loud          ref src/analyze.c:63-80
@@ -716,34 +714,24 @@ __device__ __forceinline__ double bl_norm(int k, double rcp, double rcp_lo) {
 #define BL_FIR_SEL(MODE, X, FC) ((MODE) == 2 ? BL_FIR_FOLD(X, FC) : (MODE) == 1 ? BL_FIR_FUSED(X) : BL_FIR(X))
 
 /* ------------------------------------------------------------------------- */
-/* k_env_windows2: normalise + FIR + DFT + ordered sum, wave-autonomous      */
+/* k_env_windows3: normalise + FIR + DFT + ordered sum, wave-autonomous        */
 /*
- * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, so the
- * ~200 VGPRs the unrolled FIR/DFT code wants fit without spilling), no workgroup barrier
- * inside the loop.  A compute wave owns 4 consecutive windows per round (one per
- * 16-lane group) and does everything for them out of its private 11.9 KB LDS slice:
- * normalise 1280 samples once, 17-tap FIR (20 outputs per lane from 36 register-held
- * inputs, written back in place), the four 512-point f64 DFTs with split re/im
+ * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, so the ~230 VGPRs
+ * the unrolled FIR / DFT code wants fit without spilling), no workgroup barrier inside the loop.
+ * A compute wave owns 4 consecutive windows per round (one per 16-lane group) and does everything
+ * for them out of its private LDS slice: 17-tap FIR, the four 512-point f64 DFTs with split re/im
  * exchanges, and the 4 x 257 power terms.  The f32-rounded, strictly ordered sum of
- * ref tempo_atk_sort.c:142-149 is a 771-deep dependent chain per window: it runs on
- * the eighth wave, one lane per window for the 28 windows of the tile, concurrently
- * with the next round of the compute waves (terms buffer handed over through two LDS
- * sequence words; waves of one workgroup are always co-resident, so the spin waits
- * cannot deadlock).
+ * ref tempo_atk_sort.c:142-149 is a 771-deep dependent chain per window: it runs on the eighth
+ * wave, one lane per window for the 28 windows of the tile, concurrently with the next round of
+ * the compute waves (terms buffer handed over through two LDS sequence words; waves of one
+ * workgroup are always co-resident, so the spin waits cannot deadlock).
  */
-#define EV2_CWAVES 7
-#define EV2_TILE (4 * EV2_CWAVES)            /* windows per tile */
-#define EV2_SLOTS 1490                       /* 18 + 1280 samples + 2 x 64 pads, + 4 x 16 window heads */
-#define EV2_HEADS 1426
-#define EV2_TROW 258                         /* terms row stride (doubles): even -> 16-byte rows */
-#define EV2_TERMS_OFF (EV2_CWAVES * EV2_SLOTS * 8)
-#define EV2_TW_OFF (EV2_TERMS_OFF + EV2_TILE * EV2_TROW * 8)
-#define EV2_FLAG_OFF (EV2_TW_OFF + 2 * 256 * 16)
-#define EV2_LDS_BYTES (EV2_FLAG_OFF + 64)
+#define EV_CWAVES 7
+#define EV_TILE (4 * EV_CWAVES)             /* windows per tile */
+#define EV_TROW 258                          /* terms row stride (doubles): even -> 16-byte rows */
 
-/* cross-lane move of a double through DPP (two 32-bit moves).  CTRL 0x138 = wave_shr:1
- * (lane i reads lane i-1), 0x110+m = row_shr:m inside each 16-lane row; lanes without a
- * source read 0 (bound_ctrl) */
+/* cross-lane move of a double through DPP (two 32-bit moves).  CTRL 0x110+m = row_shr:m inside
+ * each 16-lane row, 0x140 = row_mirror; lanes without a source read 0 (bound_ctrl) */
 template <int CTRL> __device__ __forceinline__ double bl_dpp_f64(double v) {
   const unsigned long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b & 0xFFFFFFFFull), CTRL, 0xF, 0xF, true);
@@ -760,278 +748,21 @@ template <int CTRL> __device__ __forceinline__ double bl_dpp_f64_old(double old,
   return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
-/* LDS slot of tile-local sample j of a compute wave: two pads after every 20 samples make
- * the per-lane stride 22 doubles (44 banks: conflict-free 16-byte stores per 8-lane group)
- * and keep every even sample 16-byte aligned, so that the (re, im) = (y[2m], y[2m+1]) pairs
- * of the DFT input are single ds_read_b128 (4 LDS cycles instead of the 8 of ds_read2_b64) */
-__device__ __forceinline__ int ev2_slot(int j) { return 18 + j + 2 * ((j * 3277) >> 16); }
-
 /* Hand-over fences between waves of one workgroup: everything handed over lives in LDS, so
  * only the LDS counter has to drain.  A workgroup-scope fence also waits for vmcnt(0), i.e.
  * for the summing wave's global stores of the finished energies (and for prefetches in
  * flight) — ~1.5 k cycles of HBM latency on the critical path of every tile. */
-__device__ __forceinline__ void ev2_lds_release() {
+__device__ __forceinline__ void ev_lds_release() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
-__device__ __forceinline__ void ev2_lds_acquire() {
+__device__ __forceinline__ void ev_lds_acquire() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-__device__ __forceinline__ void ev2_wave_sync() {
+__device__ __forceinline__ void ev_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-/* DBG = true adds the measurement aids of BL_AMD_ENV_DBG (bit 0: skip the ordered sums,
- * bit 1: skip the compute, bit 2: clock probe); the production instantiation carries none
- * of it (device printf alone costs registers). */
-template <bool DBG>
-__global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
-    const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
-    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc, int dbg_arg) {
-  const int dbg = DBG ? dbg_arg : 0;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *terms = reinterpret_cast<double *>(smem + EV2_TERMS_OFF); /* [EV2_TILE][257] */
-  c2d *tw256 = reinterpret_cast<c2d *>(smem + EV2_TW_OFF);
-  c2d *tw512 = tw256 + 256;
-  /* flags[0..6]: last tile sequence whose terms compute wave c has published;
-   * flags[8]: last tile sequence the summing wave has consumed.  Typed as LDS (address
-   * space 3) so that the polls are ds_read_b32: through a generic volatile pointer hipcc
-   * emits flat loads with sc0 sc1 and waits on vmcnt as well. */
-  typedef __attribute__((address_space(3))) volatile int lds_vint;
-  lds_vint *flags = (lds_vint *)(smem + EV2_FLAG_OFF);
-
-  const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63, g = ln >> 4, l = ln & 15;
-  const bl_dsong sg = songs[blockIdx.y];
-  const bl_dstats st = stats[blockIdx.y];
-  const int16_t *p = pcm + sg.pcm_off;
-  if (tid < 256) {
-    tw256[tid] = tb.tw256_d[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
-    tw512[tid] = tb.tw512_d[tid];
-  }
-  if (tid < 16) flags[tid] = 0;
-  __syncthreads();
-
-  const int n_tiles = (sg.n_windows + EV2_TILE - 1) / EV2_TILE;
-  const int n_used = 256 * (sg.n_windows + 1);
-  int seq = 0;
-  const long long dbg_c0 = (DBG && (dbg & 4)) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  const long long dbg_w0 = (DBG && (dbg & 4)) ? (long long)wall_clock64() : 0;
-
-  if (wave == EV2_CWAVES) {
-    /* ---- summing wave ---- */
-    __builtin_amdgcn_s_setprio(3);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-      ++seq;
-      for (;;) {
-        const int f = ln < EV2_CWAVES ? flags[ln] : seq;
-        if (__all(f >= seq)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      ev2_lds_acquire();
-      const int w = tile * EV2_TILE + ln;
-      if (ln < EV2_TILE && w < sg.n_windows && !(dbg & 1)) {
-        /* ref :142-151: float sum_fft += (double)|X_k|^2 for k = 0..256 in order */
-        /* the chain is ~18 cycles per term (cvt, add, cvt); the LDS reads are blocked 32
-         * terms ahead so that their latency never sits on it */
-        const double *tg = terms + ln * EV2_TROW;
-        float sum = 0.f;
-        double ta[32], tb2[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) ta[k] = tg[k];
-#pragma unroll 1
-        for (int blk = 0; blk < 8; blk += 2) {
-#pragma unroll
-          for (int k = 0; k < 32; ++k) tb2[k] = tg[32 * (blk + 1) + k];
-#pragma unroll
-          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + ta[k]);
-          if (blk + 2 < 8) {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) ta[k] = tg[32 * (blk + 2) + k];
-          }
-#pragma unroll
-          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + tb2[k]);
-        }
-        sum = (float)((double)sum + tg[256]);
-        energies[sg.env_off + w] = sum;
-        lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
-      }
-      ev2_lds_release();
-      if (ln == 0) flags[8] = seq;
-    }
-    return;
-  }
-
-  /* ---- compute waves ---- */
-  double *buf = reinterpret_cast<double *>(smem) + wave * EV2_SLOTS;
-  const int mean = st.mean;
-  const double rcp = st.rcp, rcp_lo = st.rcp_lo;
-  /* lane ln owns samples 20*ln .. 20*ln+19 of the wave's 1280 (five 8-byte loads) plus
-   * the one sample that starts its own zero-state output (lane (g, l): sample l of window
-   * g); both are fetched one round ahead so that the HBM latency hides behind the
-   * arithmetic of the current round */
-  /* this lane's 15 pass-1 twiddles W256^(l k1) live in registers (60 of the 40 + 20 the kernel
-   * had to spare below 256): read from LDS inside the round, each one put its latency in front
-   * of four dependent operations.  Pinned, because hipcc would otherwise re-read LDS in the loop. */
-  c2d w1r[16];
-#pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) {
-    w1r[k1] = tw256[k1 * 16 + l];
-    asm volatile("" : "+v"(w1r[k1].re), "+v"(w1r[k1].im));
-  }
-  uint2 pre[5];
-  short preh;
-  /* The loads are unconditional (addresses clamped into the song, values zeroed by a
-   * select afterwards): with exec-masked loads hipcc cannot count what is outstanding and
-   * waits vmcnt(0) right after issuing the NEXT round's loads. */
-  auto fetch = [&](int tile_) {
-    const int base = (tile_ * EV2_TILE + 4 * wave) * 256;
-    const bool live = tile_ < n_tiles;
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int i0 = base + 20 * ln + 4 * u;
-      const bool ok = live && i0 + 4 <= n_used;
-      const uint2 v = *reinterpret_cast<const uint2 *>(p + (ok ? i0 : 0));
-      pre[u] = ok ? v : make_uint2(0, 0);
-    }
-    const int ih = base + 256 * g + l;
-    const bool okh = live && ih < n_used;
-    const short vh = p[okh ? ih : 0];
-    preh = okh ? vh : (short)0;
-  };
-  fetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    ++seq;
-    if (dbg & 2) { /* measurement aid: hand-off only */
-      while (flags[8] < seq - 1) __builtin_amdgcn_s_sleep(1);
-      if (ln == 0) flags[wave] = seq;
-      continue;
-    }
-    /* 1. normalise (ref :109-114) straight into registers: r[16..35] = own 20 samples,
-     *    r[0..15] = the previous lane's last 16 (DPP wave shift, no LDS round trip) */
-    double yv[20], yh;
-    {
-      double r[36];
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        const unsigned w[2] = {pre[u].x, pre[u].y};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-          r[16 + 4 * u + 2 * k] = bl_norm(lo - mean, rcp, rcp_lo);
-          r[16 + 4 * u + 2 * k + 1] = bl_norm(hi - mean, rcp, rcp_lo);
-        }
-      }
-      const double xh = bl_norm((int)preh - mean, rcp, rcp_lo);
-      fetch(tile + gridDim.x); /* next round's samples */
-#pragma unroll
-      for (int i = 0; i < 16; ++i) r[i] = bl_dpp_f64<0x138>(r[20 + i]); /* wave_shr:1 */
-      /* 2. FIR (ref :123-138): outputs 20*ln .. 20*ln+19 of the wave's 1280 */
-#pragma unroll
-      for (int i = 0; i < 20; ++i) {
-#define XR(m) r[i + 16 - (m)]
-        yv[i] = BL_FIR(XR);
-#undef XR
-      }
-      /* first 16 outputs of each window start from a zeroed delay line (ref :121):
-       * lane (g, l) filters sample l of window g with the taps that exist; tap m is the
-       * sample of lane l - m of the same 16-lane row, zero when there is none
-       * (DPP row_shr:m with bound_ctrl) */
-      double hx[17];
-      hx[0] = xh;
-      hx[1] = bl_dpp_f64<0x111>(xh);  hx[2] = bl_dpp_f64<0x112>(xh);  hx[3] = bl_dpp_f64<0x113>(xh);
-      hx[4] = bl_dpp_f64<0x114>(xh);  hx[5] = bl_dpp_f64<0x115>(xh);  hx[6] = bl_dpp_f64<0x116>(xh);
-      hx[7] = bl_dpp_f64<0x117>(xh);  hx[8] = bl_dpp_f64<0x118>(xh);  hx[9] = bl_dpp_f64<0x119>(xh);
-      hx[10] = bl_dpp_f64<0x11A>(xh); hx[11] = bl_dpp_f64<0x11B>(xh); hx[12] = bl_dpp_f64<0x11C>(xh);
-      hx[13] = bl_dpp_f64<0x11D>(xh); hx[14] = bl_dpp_f64<0x11E>(xh); hx[15] = bl_dpp_f64<0x11F>(xh);
-      hx[16] = 0.0;
-#define XH(m) hx[m]
-      yh = BL_FIR(XH);
-#undef XH
-    }
-    ev2_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
-#pragma unroll
-    for (int i = 0; i < 20; ++i) buf[22 * ln + 18 + i] = yv[i];
-    /* sample 256*(g+1)+q (q < 16) is both the tail of window g (steady state, above) and
-     * the head of window g+1 (zero state): heads live in their own 4 x 16 area */
-    buf[EV2_HEADS + ln] = yh;
-    ev2_wave_sync();
-    /* 3. DFT input of window g: lane l holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
-    double re[16], im[16];
-#pragma unroll
-    for (int m1 = 0; m1 < 16; ++m1) {
-      int s = ev2_slot(256 * g + 32 * m1 + 2 * l);
-      if (m1 == 0 && l < 8) s = EV2_HEADS + 16 * g + 2 * l;
-      re[m1] = buf[s];
-      im[m1] = buf[s + 1];
-    }
-    ev2_wave_sync(); /* window data is in registers; the slice becomes exchange space */
-    bl_fft16(re, im);
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) /* twiddles of pass 1 (bl_fft512_pass1), from registers */
-      bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w1r[k1].re, w1r[k1].im);
-    /* lane 0's twiddles are (1, -0): r * 1 - i * (-0) and r * (-0) + i * 1 are r and i exactly
-     * (only the sign of a zero can differ, and everything downstream is squared), so no select
-     * keeps them out of the multiply: that select was 60 v_cndmask per round */
-    /* transposes: rows of 18 doubles so that a lane reads its row as 8 aligned 16-byte
-     * loads (ds_read_b128: 4 LDS cycles; the ds_read2_b64 hipcc picks for unaligned pairs
-     * costs 16).  Layouts checked with tools/lds_model.py: conflict-free. */
-    double *xg = buf + g * 288; /* [16][18] doubles, re then im */
-    const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = re[bl_pos16(k1)];
-    ev2_wave_sync();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; re[2 * q] = v.x; re[2 * q + 1] = v.y; }
-    ev2_wave_sync();
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = im[bl_pos16(k1)];
-    ev2_wave_sync();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
-    ev2_wave_sync();
-    bl_fft16(re, im);
-    /* partner half rows (k0 = 8..15) as (re, im) pairs, 9 pairs per lane row */
-    double2 *pg = reinterpret_cast<double2 *>(buf) + g * 144;
-#pragma unroll
-    for (int k0 = 8; k0 < 16; ++k0)
-      pg[l * 9 + (k0 - 8)] = make_double2(re[bl_pos16(k0)], im[bl_pos16(k0)]);
-    ev2_wave_sync();
-    /* 4. the 4 x 257 power terms are computed first and only then handed to the summing
-     *    wave (once it has drained the previous tile): nothing but the 17 stores per lane
-     *    sits between the two waits of the hand-over */
-    double own[8], mir[8];
-#pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) {
-      const int sl = bl_partner_slot(l, k0);
-      double pr = re[bl_pos16(0)], pi = im[bl_pos16(0)];
-      if (sl >= 0) { const double2 v = pg[(sl >> 3) * 9 + (sl & 7)]; pr = v.x; pi = v.y; }
-      bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
-                                      own[k0], mir[k0]);
-    }
-    /* |X_128|^2 = |Z_128|^2 has no 1/4 of its own: give back the one the halved input took */
-    const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
-    const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
-    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
-    ev2_lds_acquire();
-    double *tg = terms + (4 * wave + g) * EV2_TROW;
-#pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) {
-      tg[l + 16 * k0] = own[k0];
-      tg[256 - l - 16 * k0] = mir[k0];
-    }
-    if (l == 0) tg[128] = mid;
-    ev2_lds_release();
-    ev2_wave_sync();
-    if (ln == 0) flags[wave] = seq;
-  }
-  if ((dbg & 4) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-    const long long c = (long long)__builtin_amdgcn_s_memtime() - dbg_c0;
-    const long long w = (long long)wall_clock64() - dbg_w0;
-    printf("ev2 clock probe: %lld shader cycles in %lld wall ticks (100 MHz) -> %.1f MHz, %d tiles\n", c,
-           w, (double)c / (double)w * 100.0, n_tiles);
-  }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1056,17 +787,17 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows2(
 #define EV3_BLK 288                          /* doubles per block: 16 rows of 16 samples + 2 pads */
 #define EV3_HEADS (5 * EV3_BLK)
 #define EV3_SLOTS (EV3_HEADS + 64)           /* + 4 x 16 window heads */
-#define EV3_TERMS_OFF (EV2_CWAVES * EV3_SLOTS * 8)
-#define EV3_TW_OFF (EV3_TERMS_OFF + EV2_TILE * EV2_TROW * 8)
+#define EV3_TERMS_OFF (EV_CWAVES * EV3_SLOTS * 8)
+#define EV3_TW_OFF (EV3_TERMS_OFF + EV_TILE * EV_TROW * 8)
 #define EV3_FLAG_OFF (EV3_TW_OFF + 2 * 256 * 16)
 #define EV3_LDS_BYTES (EV3_FLAG_OFF + 64)
 
 template <int FIR_MODE>
-__global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
+__global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
     const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *terms = reinterpret_cast<double *>(smem + EV3_TERMS_OFF); /* [EV2_TILE][257] */
+  double *terms = reinterpret_cast<double *>(smem + EV3_TERMS_OFF); /* [EV_TILE][257] */
   c2d *tw256 = reinterpret_cast<c2d *>(smem + EV3_TW_OFF);
   c2d *tw512 = tw256 + 256;
   typedef __attribute__((address_space(3))) volatile int lds_vint;
@@ -1085,30 +816,30 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
 
   /* rounds of four windows, split evenly over the compute waves of the song's workgroups */
   const int n_rounds = (sg.n_windows + 3) / 4;
-  const int n_units = EV2_CWAVES * (int)gridDim.x;
+  const int n_units = EV_CWAVES * (int)gridDim.x;
   auto run_begin = [&](int u) -> int { return (int)((long long)n_rounds * u / n_units); };
-  const int u0 = EV2_CWAVES * (int)blockIdx.x;
+  const int u0 = EV_CWAVES * (int)blockIdx.x;
   int steps = 0;
-  for (int c = 0; c < EV2_CWAVES; ++c) steps = max(steps, run_begin(u0 + c + 1) - run_begin(u0 + c));
+  for (int c = 0; c < EV_CWAVES; ++c) steps = max(steps, run_begin(u0 + c + 1) - run_begin(u0 + c));
   const int n_used = 256 * (sg.n_windows + 1);
   int seq = 0;
 
-  if (wave == EV2_CWAVES) {
+  if (wave == EV_CWAVES) {
     /* ---- summing wave: lane 4 c + q sums window q of compute wave c's current round ---- */
     __builtin_amdgcn_s_setprio(3);
-    const int c = min(ln >> 2, EV2_CWAVES - 1);
+    const int c = min(ln >> 2, EV_CWAVES - 1);
     const int r0 = run_begin(u0 + c), r1 = run_begin(u0 + c + 1);
     for (int s = 0; s < steps; ++s) {
       ++seq;
       for (;;) {
-        const int f = ln < EV2_CWAVES ? flags[ln] : seq;
+        const int f = ln < EV_CWAVES ? flags[ln] : seq;
         if (__all(f >= seq)) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      ev2_lds_acquire();
+      ev_lds_acquire();
       const int rho = r0 + s, w = 4 * rho + (ln & 3);
-      if (ln < EV2_TILE && rho < r1 && w < sg.n_windows) {
-        const double *tg = terms + ln * EV2_TROW;
+      if (ln < EV_TILE && rho < r1 && w < sg.n_windows) {
+        const double *tg = terms + ln * EV_TROW;
         float sum = 0.f;
         double ta[32], tb2[32];
 #pragma unroll
@@ -1130,7 +861,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
         energies[sg.env_off + w] = sum;
         lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
       }
-      ev2_lds_release();
+      ev_lds_release();
       if (ln == 0) flags[8] = seq;
     }
     return;
@@ -1266,11 +997,11 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
     const int xa = base5 + g, xb = xa + 1;
     const int pa = xa >= 5 ? xa - 5 : xa, pb = xb >= 5 ? xb - 5 : xb;
     double *blk_a = buf + pa * EV3_BLK, *blk_b = buf + pb * EV3_BLK;
-    ev2_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
+    ev_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
 #pragma unroll
     for (int i = 0; i < 16; ++i) blk_b[18 * l + i] = yv[i];
     buf[EV3_HEADS + ln] = yh;
-    ev2_wave_sync();
+    ev_wave_sync();
     /* 3. DFT input of window g: lane l holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
     double re[16], im[16];
     {
@@ -1284,7 +1015,7 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
 #pragma unroll
       for (int m1 = 8; m1 < 16; ++m1) { re[m1] = ib[36 * (m1 - 8)]; im[m1] = ib[36 * (m1 - 8) + 1]; }
     }
-    ev2_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
+    ev_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
     bl_fft16(re, im);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
@@ -1295,16 +1026,16 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
     const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = re[bl_pos16(k1)];
-    ev2_wave_sync();
+    ev_wave_sync();
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; re[2 * q] = v.x; re[2 * q + 1] = v.y; }
-    ev2_wave_sync();
+    ev_wave_sync();
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = im[bl_pos16(k1)];
-    ev2_wave_sync();
+    ev_wave_sync();
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
-    ev2_wave_sync();
+    ev_wave_sync();
     bl_fft16(re, im);
     /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16 —
      * a mirror of the 16-lane row followed by a rotation by one, two DPP moves per dword and no LDS
@@ -1325,16 +1056,16 @@ __global__ __launch_bounds__(64 * (EV2_CWAVES + 1)) void k_env_windows3(
     const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
     const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
     while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
-    ev2_lds_acquire();
-    double *tg = terms + (4 * wave + g) * EV2_TROW;
+    ev_lds_acquire();
+    double *tg = terms + (4 * wave + g) * EV_TROW;
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
       tg[l + 16 * k0] = own[k0];
       tg[256 - l - 16 * k0] = mir[k0];
     }
     if (l == 0) tg[128] = mid;
-    ev2_lds_release();
-    ev2_wave_sync();
+    ev_lds_release();
+    ev_wave_sync();
     if (ln == 0) flags[wave] = seq;
     base5 = base5 == 0 ? 4 : base5 - 1; /* (4 (rho + 1)) mod 5 */
   }
@@ -1413,10 +1144,10 @@ __global__ __launch_bounds__(192) void k_env_tail(const bl_dsong *__restrict__ s
       for (int q = 0; q < 19; ++q) a.pair(19 * kb + q < nw ? cur[q] : 0.0, ye[2 * q], ye[2 * q + 1]);
       /* the buffer is free once the block before the previous one has been consumed */
       while (__builtin_amdgcn_readfirstlane(flags[1]) < kb - 1) __builtin_amdgcn_s_sleep(1);
-      ev2_lds_acquire();
+      ev_lds_acquire();
 #pragma unroll
       for (int q = 0; q < 38; ++q) yo[q * 64] = ye[q];
-      ev2_lds_release();
+      ev_lds_release();
       bl_wave_sync();
       if (lane == 0) flags[0] = kb + 1;
     };
@@ -1438,7 +1169,7 @@ __global__ __launch_bounds__(192) void k_env_tail(const bl_dsong *__restrict__ s
     for (int kb = 0; kb < n_blocks; ++kb) {
       while (__builtin_amdgcn_readfirstlane(flags[0]) < kb + 1) __builtin_amdgcn_s_sleep(1);
       while (__builtin_amdgcn_readfirstlane(flags[3]) < kb - 1) __builtin_amdgcn_s_sleep(1);
-      ev2_lds_acquire();
+      ev_lds_acquire();
       const double *yin = yblk[kb & 1] + lane;
       const int j = 38 * kb;
       bl_tail_fifo f;
@@ -1462,7 +1193,7 @@ __global__ __launch_bounds__(192) void k_env_tail(const bl_dsong *__restrict__ s
         }
       }
       ocnt[kb & 1][lane] = f.count;
-      ev2_lds_release();
+      ev_lds_release();
       bl_wave_sync();
       if (lane == 0) { flags[1] = kb + 1; flags[2] = kb + 1; }
     }
@@ -1479,7 +1210,7 @@ __global__ __launch_bounds__(192) void k_env_tail(const bl_dsong *__restrict__ s
   c.init(sg.nb_frames, rings_c + lane, 64);
   for (int kb = 0; kb < n_blocks; ++kb) {
     while (__builtin_amdgcn_readfirstlane(flags[2]) < kb + 1) __builtin_amdgcn_s_sleep(1);
-    ev2_lds_acquire();
+    ev_lds_acquire();
     const double *oin = oblk[kb & 1] + lane;
     const int cnt = ocnt[kb & 1][lane];
     if (cnt == 38 && c.chunk_ok()) {
@@ -1489,7 +1220,7 @@ __global__ __launch_bounds__(192) void k_env_tail(const bl_dsong *__restrict__ s
         if (q < cnt) c.push(oin[q * 64]);
     }
     if (valid && c.taken == N && cnt > 0) c.finish(); /* the block that delivered the song's last output */
-    ev2_lds_release();
+    ev_lds_release();
     bl_wave_sync();
     if (lane == 0) flags[3] = kb + 1;
   }
@@ -1559,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vec
     const float4 a = vecs[row_begin + row];
     float *orow = out + (size_t)row * n;
     float r[4];
-    if (SQ == 3) { /* measurement aid (BL_AMD_SQRT_VARIANT=3): the store stream alone, no arithmetic */
+    if (SQ == 3) { /* measurement builds only (BL_AMD_MEASURE): the store stream alone, no arithmetic */
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[k] = a.x;
     } else if (COSINE) {
@@ -1769,10 +1500,6 @@ bl_tables blk_tables_bind(const void *d_mem) {
 }
 
 int blk_configure_device(void) {
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows2<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV2_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<1>),
@@ -1825,14 +1552,19 @@ extern "C" int bl_amd_set_fir_mode(int mode) {
 
 namespace {
 
-/* measurement aid: BL_AMD_SQRT_VARIANT=0|1|2|3 picks the root of the distance kernel at run time
- * (0 = the compiler's sqrtf only, 3 = no arithmetic at all: the store stream alone — results
- * invalid); unset = the compiled default BL_SQRT_VARIANT.  rocprofv3 at N = 10 000, us per launch:
- * 78.9 / 71.2 / 70.7 / 66.6 (tools/dist_bench.py, profiles/r03_distance.json). */
+/* Which root the distance kernel uses: the compiled default BL_SQRT_VARIANT (bl_sqrt.h).  Only a
+ * measurement build (make measure: -DBL_AMD_MEASURE, tools/dist_bench.py) also reads
+ * BL_AMD_SQRT_VARIANT=0|1|2|3 at run time — 0 = the compiler's sqrtf only, 3 = no arithmetic at
+ * all, the store stream alone (results invalid).  The product build ignores the variable.
+ * rocprofv3 at N = 10 000, us per launch: 78.9 / 71.2 / 70.7 / 66.6 (profiles/r03_distance.json). */
 int blk_sqrt_variant() {
+#ifdef BL_AMD_MEASURE
   const char *e = getenv("BL_AMD_SQRT_VARIANT");
   const int v = e && *e ? atoi(e) : BL_SQRT_VARIANT;
   return v < 0 || v > 3 ? BL_SQRT_VARIANT : v;
+#else
+  return BL_SQRT_VARIANT;
+#endif
 }
 
 int grid_x_for(long long units_max, int n_songs, int blocks_per_cu, int n_cu) {
@@ -1878,24 +1610,17 @@ int blk_analyze(const blk_analyze_args &a) {
       /* one 512-thread workgroup per CU; the blocks of a song split its rounds of four windows
        * into contiguous runs, one per compute wave: at least four rounds per run, so that the
        * block a run filters before its first round stays a small part of it */
-      const int gx2 = grid_x_for(std::max(1, (2 * max_frames) / (4 * 4 * EV2_CWAVES)), n_songs, 2, a.n_cu);
-      static const bool old_env = getenv("BL_AMD_ENV_OLD") != nullptr; /* A/B aid: the round-robin kernel */
-      if (a.env_dbg)
-        hipLaunchKernelGGL(k_env_windows2<true>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                           EV2_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc,
-                           a.env_dbg);
-      else if (!old_env && blk_fir_mode() == 2)
-        hipLaunchKernelGGL(k_env_windows3<2>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+      const int gx2 = grid_x_for(std::max(1, (2 * max_frames) / (4 * 4 * EV_CWAVES)), n_songs, 2, a.n_cu);
+      const int fir_mode = blk_fir_mode();
+      if (fir_mode == 2)
+        hipLaunchKernelGGL(k_env_windows3<2>, dim3(gx2, n_songs), dim3(64 * (EV_CWAVES + 1)),
                            EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
-      else if (!old_env && blk_fir_mode() == 1)
-        hipLaunchKernelGGL(k_env_windows3<1>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
-      else if (!old_env)
-        hipLaunchKernelGGL(k_env_windows3<0>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
+      else if (fir_mode == 1)
+        hipLaunchKernelGGL(k_env_windows3<1>, dim3(gx2, n_songs), dim3(64 * (EV_CWAVES + 1)),
                            EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
       else
-        hipLaunchKernelGGL(k_env_windows2<false>, dim3(gx2, n_songs), dim3(64 * (EV2_CWAVES + 1)),
-                           EV2_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc, 0);
+        hipLaunchKernelGGL(k_env_windows3<0>, dim3(gx2, n_songs), dim3(64 * (EV_CWAVES + 1)),
+                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
     }
     hipStream_t ts = stream;
     if ((what & 3) && a.side) { /* something to overlap with */
@@ -1953,22 +1678,27 @@ int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int 
     const int cnt = n_rows - r0 < chunk ? n_rows - r0 : chunk;
     const int gy = (cnt + BL_PW_ROWS - 1) / BL_PW_ROWS;
     Mark m(mark, mark_user, PK_DIST, s);
-    const int sq = blk_sqrt_variant();
     if (cosine)
       hipLaunchKernelGGL((k_pairwise<true, 0>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
-    else if (sq == 0)
+#ifdef BL_AMD_MEASURE
+    else if (blk_sqrt_variant() == 0)
       hipLaunchKernelGGL((k_pairwise<false, 0>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
-    else if (sq == 3)
+    else if (blk_sqrt_variant() == 3)
       hipLaunchKernelGGL((k_pairwise<false, 3>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
-    else if (sq == 2)
+    else if (blk_sqrt_variant() == 2)
       hipLaunchKernelGGL((k_pairwise<false, 2>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
     else
       hipLaunchKernelGGL((k_pairwise<false, 1>), dim3(gx, gy), dim3(256), 0, s, v, n, row_begin + r0, cnt,
                          d_out + (size_t)r0 * n);
+#else
+    else
+      hipLaunchKernelGGL((k_pairwise<false, BL_SQRT_VARIANT>), dim3(gx, gy), dim3(256), 0, s, v, n,
+                         row_begin + r0, cnt, d_out + (size_t)r0 * n);
+#endif
   }
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;

@@ -79,7 +79,7 @@ struct blk_analyze_args {
   float *energies;           /* device scratch, one per envelope slot */
   double *lc;                /* device scratch, one per envelope slot */
   bl_amd_song_result *results;
-  int n_songs, max_n, what, n_cu, env_dbg;
+  int n_songs, max_n, what, n_cu;
   bl_tables tb;
   hipStream_t stream, side;  /* side == nullptr: envelope tail on `stream` */
   hipEvent_t ev_env, ev_tail;

@@ -46,7 +46,6 @@ struct bl_amd_ctx {
   std::mutex mu;
   int device = 0;
   int n_cu = 256;
-  int env_dbg = 0;
   int group_songs = BL_GROUP_SONGS_MAX;
   hipStream_t side = nullptr; /* envelope tail runs here, beside the frequency pass */
   hipEvent_t ev_env = nullptr, ev_tail = nullptr;

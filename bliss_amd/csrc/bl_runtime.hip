@@ -87,8 +87,6 @@ int ctx_init(bl_amd_ctx *c, int device) {
   c->tb = blk_tables_bind(c->tables_mem);
   if (blk_configure_device() != BL_OK) return BL_UNEXPECTED;
   {
-    const char *d = getenv("BL_AMD_ENV_DBG"); /* bit 0: skip the ordered sums, bit 1: skip compute */
-    c->env_dbg = d ? atoi(d) : 0;
     /* songs per launch group; lowered by the tests to exercise the multi-group path */
     const char *gs = getenv("BL_AMD_GROUP_SONGS");
     int g = gs ? atoi(gs) : BL_GROUP_SONGS_MAX;
@@ -331,10 +329,13 @@ int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_de
     a.max_n = max_n[gi];
     a.what = what;
     a.n_cu = c->n_cu;
-    a.env_dbg = c->env_dbg;
     a.tb = c->tb;
     a.stream = stream;
-    a.side = getenv("BL_AMD_NO_SIDE") ? nullptr : c->side; /* measurement aid: serialise the tail */
+#ifdef BL_AMD_MEASURE
+    a.side = getenv("BL_AMD_NO_SIDE") ? nullptr : c->side; /* measurement builds only: serialise the tail */
+#else
+    a.side = c->side;
+#endif
     a.ev_env = c->ev_env;
     a.ev_tail = c->ev_tail;
     a.mark = c->prof ? mark_cb : nullptr;
@@ -921,27 +922,36 @@ int bl_amd_analyze_files(const char *const *filenames, int n_files, struct bl_so
   if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
   n_threads = std::min(n_threads, n_files);
   const size_t WAVE_BYTES = (size_t)1 << 30; /* decoded PCM per wave */
+  /* The decoders run ahead of the wave being analysed by at most AHEAD_BYTES of decoded PCM (and AHEAD_FILES
+   * files): a byte bound, because a file bound alone lets 768 ten-minute songs (40 GB) pile up on the host.
+   * The file the consumer is waiting for is always taken, whatever the budget says, so the two cannot deadlock. */
+  const size_t AHEAD_BYTES = 3 * WAVE_BYTES;
   const int WAVE_FILES = 512, AHEAD_FILES = 768; /* AHEAD_FILES >= WAVE_FILES: a wave never waits for a file the decoders may not take */
 
   std::mutex mu;
   std::condition_variable cv;
   std::vector<signed char> state((size_t)n_files, 0); /* 0 pending, 1 decoded, -1 failed */
   int next = 0, limit = std::min(n_files, AHEAD_FILES); /* decoders take indices below `limit` */
+  int want = 0;          /* the file the consumer needs next */
+  size_t ahead_bytes = 0; /* decoded PCM not yet released by the consumer */
   bool stop = false;
   auto decoder = [&] {
     for (;;) {
       int i;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return stop || next < limit; });
+        cv.wait(lk, [&] { return stop || next >= n_files || (next < limit && (ahead_bytes < AHEAD_BYTES || next <= want)); });
         if (stop || next >= n_files) return;
         i = next++;
       }
-      const int rc = filenames[i] ? bl_audio_decode(filenames[i], &songs[i]) : BL_UNEXPECTED;
+      /* bl_audio_decode initialises every field of songs[i] itself and fails on a NULL name: the caller's
+       * structs may be uninitialised (ref tests/test_analyze.c:27-28), so it must run for every index */
+      const int rc = bl_audio_decode(filenames[i], &songs[i]);
       if (rc != BL_OK) fprintf(stderr, "Couldn't decode song\n"); /* ref src/analyze.c:83 */
       {
         std::lock_guard<std::mutex> lk(mu);
         state[(size_t)i] = rc == BL_OK ? 1 : -1;
+        if (rc == BL_OK && songs[i].sample_array) ahead_bytes += (size_t)songs[i].nSamples * 2;
       }
       cv.notify_all();
     }
@@ -963,7 +973,11 @@ int bl_amd_analyze_files(const char *const *filenames, int n_files, struct bl_so
     while (e < n_files && (int)(e - done) < WAVE_FILES && bytes < WAVE_BYTES) {
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return state[(size_t)e] != 0; });
+        if (state[(size_t)e] == 0) {
+          want = e;
+          cv.notify_all();
+          cv.wait(lk, [&] { return state[(size_t)e] != 0; });
+        }
       }
       if (codes) codes[e] = BL_UNEXPECTED;
       if (state[(size_t)e] == 1) {
@@ -1009,11 +1023,19 @@ int bl_amd_analyze_files(const char *const *filenames, int n_files, struct bl_so
         }
       }
     }
-    if (!keep_pcm)
-      for (int i = done; i < e; ++i) {
+    size_t released = 0;
+    for (int i = done; i < e; ++i) {
+      if (state[(size_t)i] == 1 && songs[i].sample_array) released += (size_t)songs[i].nSamples * 2;
+      if (!keep_pcm) {
         free(songs[i].sample_array);
         songs[i].sample_array = NULL;
       }
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      ahead_bytes -= std::min(released, ahead_bytes);
+    }
+    cv.notify_all();
     done = e;
   }
   {

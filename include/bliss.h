@@ -30,6 +30,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library itself is built with -fvisibility=hidden: what these headers declare is its whole export list */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -142,6 +146,9 @@ int bl_variance(int16_t *sample_array, int nSamples, int mean);
 void bl_rectangular_filter(double *sample_array_out, double *sample_array_in,
                            int nSamples, int smooth_width);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library itself is built with -fvisibility=hidden: what these headers declare is its whole export list */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* One decoded song inside a PCM arena: what the analyzers read from
  * struct bl_song (ref include/bliss.h:49-67): sample_array, nSamples,
@@ -285,6 +289,9 @@ long long bl_amd_last_energies(float *h_out, long long max_elems);
  * state.  Explicit contexts are released by bl_amd_ctx_destroy. */
 void bl_amd_shutdown(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,18 @@ def test_every_declared_symbol_is_exported(lib):
     assert names == set(_lib.SYMBOLS), names ^ set(_lib.SYMBOLS)
 
 
+def test_nothing_else_is_exported(lib):
+    """`nm -D`: the dynamic symbol table holds the 15 symbols of the reference's libbliss.so (ref include/bliss.h:80-290)
+    and the bl_amd_* extension — no kernels, launch-layer functions, decoder internals or libstdc++ instantiations
+    (built with -fvisibility=hidden and the export list bliss_amd/csrc/libbliss_amd.map)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, stdout=subprocess.PIPE, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    declared = _declared("bliss.h") | _declared("bliss_amd.h")
+    assert exported == declared, sorted(exported ^ declared)
+    assert len([n for n in exported if not n.startswith("bl_amd_")]) == 15
+
+
 def test_struct_layout_matches_reference():
     # ref include/bliss.h:49-67 on x86-64: 120 bytes, offsets from SURVEY.md §8b
     S = _lib.BlSong

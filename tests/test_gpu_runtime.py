@@ -107,10 +107,11 @@ print(json.dumps({"enqueue": t1 - t0, "total": t2 - t0}))
     assert t["enqueue"] < 0.5 * t["total"], t     # ~14 ms of kernels behind a sub-millisecond enqueue
 
 
-def test_both_envelope_kernels_agree(tmp_path):
-    """k_env_windows3 (contiguous runs, ring of blocks) and its predecessor k_env_windows2 (selected by
-    BL_AMD_ENV_OLD=1 in a fresh process) give identical records and identical window energies: mixed
-    lengths and channel counts, a song shorter than one run, few songs (several workgroups per song)."""
+def test_measurement_switches_are_ignored_by_the_product_build(tmp_path):
+    """The result-invalidating measurement aids (BL_AMD_SQRT_VARIANT=3: the distance kernel's store stream alone,
+    BL_AMD_ENV_DBG: ordered sums skipped, BL_AMD_ENV_OLD, BL_AMD_NO_SIDE) only exist in `make measure` builds
+    (-DBL_AMD_MEASURE); the shipped library must give the same records, window energies and distance matrix
+    whether those variables are set or not."""
     code = r'''
 import sys, hashlib
 import numpy as np
@@ -132,17 +133,20 @@ valid, off = [], 0
 for nb, nw in zip(r["nb_frames"], r["n_windows"]):
     valid.append(e[off:off + int(nw)]); off += int(nb)
 assert off == n
-print(n, hashlib.md5(np.concatenate(valid).tobytes()).hexdigest())
+vecs = np.stack([r["tempo"], r["amplitude"], r["frequency"], r["attack"]], axis=1).astype(np.float32)
+d = bliss_amd.distance_matrix(vecs)
+print(n, hashlib.md5(np.concatenate(valid).tobytes()).hexdigest(), hashlib.md5(np.ascontiguousarray(d).tobytes()).hexdigest())
 ''' % ROOT
     outs = {}
-    for tag, env in (("new", {}), ("old", {"BL_AMD_ENV_OLD": "1"})):
+    switches = {"BL_AMD_SQRT_VARIANT": "3", "BL_AMD_ENV_DBG": "3", "BL_AMD_ENV_OLD": "1", "BL_AMD_NO_SIDE": "1"}
+    for tag, env in (("plain", {}), ("switches", switches)):
         f = str(tmp_path / f"{tag}.npy")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), text=True,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = (np.load(f), r.stdout.strip().splitlines()[-1])
-    _same(outs["new"][0], outs["old"][0])
-    assert outs["new"][1] == outs["old"][1] and not outs["new"][1].startswith("0 "), outs
+    _same(outs["plain"][0], outs["switches"][0])
+    assert outs["plain"][1] == outs["switches"][1] and not outs["plain"][1].startswith("0 "), outs
 
 
 def test_host_transfer_modes_and_s32(gpu_lib, oracle):
@@ -315,3 +319,15 @@ def test_analyze_files_equals_the_per_file_loop(gpu_lib, oracle, tmp_path):
     # keep_pcm: the decoded samples stay with the song
     recs2, _ = bliss_amd.analyze_files(order[:2], n_threads=1, keep_pcm=True)
     assert recs2[0]["pcm"].size == recs2[0]["nSamples"] == 488138
+    # a NULL name among the files, song structs full of garbage (callers pass uninitialised structs, ref
+    # tests/test_analyze.c:27-28): reported for that file only, every pointer field NULL afterwards
+    names = (C.c_char_p * 3)(order[0].encode(), None, order[1].encode())
+    songs = (_lib.BlSong * 3)()
+    C.memset(songs, 0xAB, C.sizeof(songs))
+    codes3 = (C.c_int * 3)()
+    assert gpu_lib.bl_amd_analyze_files(names, 3, songs, codes3, 2, 0) == 2
+    assert codes3[1] == _lib.BL_UNEXPECTED and codes3[0] == codes[0] and codes3[2] == codes[1]
+    assert not songs[1].sample_array and songs[1].title is None and songs[1].filename is None
+    assert songs[0].force_vector.tempo == recs[0]["force_vector"]["tempo"]
+    for sg in songs:
+        gpu_lib.bl_free_song(C.byref(sg))

@@ -2,6 +2,8 @@
 """The 10 000 x 10 000 bl_distance / bl_cosine_similarity matrices (BASELINE configs[3]) timed
 with HIP events around the kernel (bl_amd_profile), per square-root variant of the distance
 kernel (BL_AMD_SQRT_VARIANT), plus the exhaustive self-test of the variant.  One JSON object.
+The variants only exist in the measurement build (`make -C bliss_amd/csrc measure`, -DBL_AMD_MEASURE), which
+this tool builds if needed and loads through BLISS_AMD_LIB; the product library ignores the variable.
 usage: python tools/dist_bench.py [--n 10000] [--reps 50]"""
 import argparse
 import ctypes as C
@@ -11,6 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+MEASURE_LIB = os.path.join(ROOT, "bliss_amd", "libbliss_amd_measure.so")
 
 
 def main():
@@ -19,6 +22,9 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--variants", default="0,1,2,3")
     a = ap.parse_args()
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "bliss_amd", "csrc"), "measure"], check=True)
+    os.environ["BLISS_AMD_LIB"] = MEASURE_LIB
     import torch
     import bliss_amd
     lib = bliss_amd.load()

@@ -6,6 +6,9 @@ PAT=${*:-freq_frames env_windows pcm_scan}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmcq
 rm -rf $OUT; mkdir -p $OUT
+# BL_AMD_NO_SIDE (the envelope tail serialised behind the other kernels) exists in the measurement build only
+make -s -C $ROOT/bliss_amd/csrc measure
+export BLISS_AMD_LIB=$ROOT/bliss_amd/libbliss_amd_measure.so
 cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
