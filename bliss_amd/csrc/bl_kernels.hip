@@ -790,20 +790,51 @@ __device__ __forceinline__ void ev_wave_sync() {
 #define EV3_TERMS_OFF (EV_CWAVES * EV3_SLOTS * 8)
 #define EV3_TW_OFF (EV3_TERMS_OFF + EV_TILE * EV_TROW * 8)
 #define EV3_FLAG_OFF (EV3_TW_OFF + 2 * 256 * 16)
-#define EV3_LDS_BYTES (EV3_FLAG_OFF + 64)
+#define EV3_ZERO_OFF (EV3_FLAG_OFF + 128)   /* 16 bytes of zeros: the 65th term pair of a second-half lane */
+#define EV3_LDS_BYTES (EV3_ZERO_OFF + 16)
 
-template <int FIR_MODE>
+/* VAR: scheduling variants, arithmetic untouched.  The VALU of a SIMD goes to the wave with
+ * the highest s_setprio value and, among equals, to the OLDEST wave, strictly (tools/gen_ubench_issue.py: 96 % of
+ * the issue slots to the older of two busy waves): two compute waves that share a SIMD and are held in step by
+ * the tile hand-over do not share it — the older one runs its round, waits, and the younger one then runs alone
+ * with every LDS round trip of its own exposed.
+ *   bit 0  fair share: a wave publishes its progress at the phase boundaries and takes priority 2 while it is
+ *          behind the wave it shares its SIMD with, 0 while it is ahead
+ *   bit 1  the LDS exchange phases of a round (short bursts between round trips) run at priority 2, the long
+ *          arithmetic phases at 1
+ *   bit 2  measurement builds: s_memtime stamps of one workgroup's phases into `probe`
+ *   bit 3  the ordered sum in two halves on twice the lanes: a compute wave hands over the terms 0..129 of the
+ *          round it has just finished together with the terms 130..256 of the round BEFORE (kept in 16 registers for
+ *          one round); the summing wave adds the first halves on lanes 0-27 and, continuing from the partial sums of
+ *          its previous step, the second halves on lanes 32-59 — 390 dependent instructions per tile instead of 771
+ *          for the same additions in the same order.  The energies leave one step later. */
+#define EV_PROBE_ROUNDS 16
+#define EV_PROBE_SLOTS 12
+#ifndef BL_ENV_VARIANT
+#define BL_ENV_VARIANT 8 /* the variant the product launches */
+#endif
+template <int FIR_MODE, int VAR>
 __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
-    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc) {
+    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc, long long *probe) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *terms = reinterpret_cast<double *>(smem + EV3_TERMS_OFF); /* [EV_TILE][257] */
   c2d *tw256 = reinterpret_cast<c2d *>(smem + EV3_TW_OFF);
   c2d *tw512 = tw256 + 256;
   typedef __attribute__((address_space(3))) volatile int lds_vint;
-  lds_vint *flags = (lds_vint *)(smem + EV3_FLAG_OFF); /* as in k_env_windows2 */
+  lds_vint *flags = (lds_vint *)(smem + EV3_FLAG_OFF); /* [0..6] published by the compute waves, [8] by the summing wave */
+  lds_vint *prog = flags + 16;                          /* VAR bit 0: progress words of the compute waves */
 
-  const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63, g = ln >> 4, l = ln & 15;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, g = ln >> 4, l = ln & 15;
+  const bool probing = (VAR & 4) && blockIdx.x == 0 && blockIdx.y == 0 && probe != nullptr;
+  auto stamp = [&](int round, int slot) {
+    if (VAR & 4) {
+      __builtin_amdgcn_sched_barrier(0); /* no arithmetic moves across a stamp */
+      if (probing && round < EV_PROBE_ROUNDS && ln == 0)
+        probe[(wave * EV_PROBE_ROUNDS + round) * EV_PROBE_SLOTS + slot] = (long long)__builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   const bl_dsong sg = songs[blockIdx.y];
   const bl_dstats st = stats[blockIdx.y];
   const int16_t *p = pcm + sg.pcm_off;
@@ -811,7 +842,8 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     tw256[tid] = tb.tw256_d[((tid & 15) * (tid >> 4)) & 255];
     tw512[tid] = tb.tw512_d[tid];
   }
-  if (tid < 16) flags[tid] = 0;
+  if (tid < 36) flags[tid] = 0; /* the two sets of sequence words and the zero pair behind them */
+  if ((VAR & 8) && tid < EV_TILE) terms[tid * EV_TROW + 257] = 0.0; /* the pad behind term 256: read as a term by bit 3 */
   __syncthreads();
 
   /* rounds of four windows, split evenly over the compute waves of the song's workgroups */
@@ -829,14 +861,88 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     __builtin_amdgcn_s_setprio(3);
     const int c = min(ln >> 2, EV_CWAVES - 1);
     const int r0 = run_begin(u0 + c), r1 = run_begin(u0 + c + 1);
+    if (VAR & 8) {
+      /* Step st (1-based): every compute wave has published st.  Lane i < 28 (row i) adds terms 0..129 of round st
+       * starting from 0 and keeps the partial sum; lane 32 + i takes the partial sum lane i made in step st - 1 and
+       * continues round st - 1 over terms 130..256, then stores the energy.  The second-half lanes read 127 terms and
+       * three zeros — (float)((double)sum + 0.0) is sum — so that every lane runs the same 130 additions.  Step
+       * steps + 1 only has second halves (the compute waves publish them after their last round). */
+      const int rowi = min(ln & 31, EV_TILE - 1);
+      const bool own = ln < 32;
+      const int c2 = min(rowi >> 2, EV_CWAVES - 1);
+      const int q0 = run_begin(u0 + c2), q1 = run_begin(u0 + c2 + 1);
+      const double2 *row = reinterpret_cast<const double2 *>(terms + rowi * EV_TROW);
+      const double2 *zero2 = reinterpret_cast<const double2 *>(smem + EV3_ZERO_OFF);
+      const double2 *tp = own ? row : row + 65;
+      const double2 *tail = own ? row + 64 : zero2;
+      float psum = 0.f;
+      for (int st = 1; st <= steps + 1; ++st) {
+        stamp(st - 1, 0);
+        for (;;) {
+          const int f = ln < EV_CWAVES ? flags[ln] : st;
+          if (__all(f >= st)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        ev_lds_acquire();
+        stamp(st - 1, 1);
+        const int rr = own ? st : st - 1; /* the round (1-based) this lane works on */
+        const int rho = q0 + rr - 1, w = 4 * rho + (ln & 3);
+        const bool live = (ln & 31) < EV_TILE && rr >= 1 && rr <= steps && rho < q1 && w < sg.n_windows;
+        /* the partial sums of the previous step move from lane i to lane 32 + i */
+        const float carried = __shfl(psum, ln & 31);
+        float sum = own ? 0.f : carried;
+        if (live) {
+          /* 65 pairs of terms, fetched 8 pairs at a time, one block ahead of the chain that adds them: lgkmcnt
+           * counts to 15, so with more than two blocks of 8 in flight the wait in front of a chain can only be
+           * for everything.  The scheduling barriers keep hipcc from sinking the loads back down in front of
+           * their uses, which would put one LDS latency per block on the step's critical path. */
+          double2 ta[8], tb2[8];
+#define EV_LOAD8(T, B) _Pragma("unroll") for (int k = 0; k < 8; ++k) T[k] = tp[8 * (B) + k];
+#define EV_SUM8(T)                                                                                      \
+  _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                       \
+    sum = (float)((double)sum + T[k].x);                                                                \
+    sum = (float)((double)sum + T[k].y);                                                                \
+  }
+#define EV_SB __builtin_amdgcn_sched_barrier(0);
+          EV_LOAD8(ta, 0) EV_LOAD8(tb2, 1) EV_SB
+          EV_SUM8(ta) EV_SB EV_LOAD8(ta, 2) EV_SB
+          EV_SUM8(tb2) EV_SB EV_LOAD8(tb2, 3) EV_SB
+          EV_SUM8(ta) EV_SB EV_LOAD8(ta, 4) EV_SB
+          EV_SUM8(tb2) EV_SB EV_LOAD8(tb2, 5) EV_SB
+          EV_SUM8(ta) EV_SB EV_LOAD8(ta, 6) EV_SB
+          EV_SUM8(tb2) EV_SB EV_LOAD8(tb2, 7)
+          const double2 tl = tail[0];
+          EV_SB
+          EV_SUM8(ta) EV_SB
+          EV_SUM8(tb2)
+          sum = (float)((double)sum + tl.x);
+          sum = (float)((double)sum + tl.y);
+#undef EV_LOAD8
+#undef EV_SUM8
+#undef EV_SB
+        }
+        /* the rows are read: hand them back before the energies are stored */
+        ev_lds_release();
+        if (ln == 0) flags[8] = st;
+        psum = sum;
+        if (live && !own) {
+          energies[sg.env_off + w] = sum;
+          lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
+        }
+        stamp(st - 1, 2);
+      }
+      return;
+    }
     for (int s = 0; s < steps; ++s) {
       ++seq;
+      stamp(s, 0);
       for (;;) {
         const int f = ln < EV_CWAVES ? flags[ln] : seq;
         if (__all(f >= seq)) break;
         __builtin_amdgcn_s_sleep(1);
       }
       ev_lds_acquire();
+      stamp(s, 1);
       const int rho = r0 + s, w = 4 * rho + (ln & 3);
       if (ln < EV_TILE && rho < r1 && w < sg.n_windows) {
         const double *tg = terms + ln * EV_TROW;
@@ -863,11 +969,32 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
       }
       ev_lds_release();
       if (ln == 0) flags[8] = seq;
+      stamp(s, 2);
     }
     return;
   }
 
   /* ---- compute waves ---- */
+  /* phase boundary k (0..5) of round seq: publish, compare with what the partner had published one boundary
+   * ago (the read issued then has long landed), choose the priority for the phase that starts here */
+  const int partner = wave < 3 ? wave + 4 : wave - 4; /* waves w and w + 4 share SIMD w; wave 3 shares with the summing wave */
+  int seen = 0;
+  auto phase = [&](int k, bool exchange) {
+    if (VAR & 1) {
+      const int P = 6 * seq + k;
+      if (wave != 3) {
+        const int theirs = __builtin_amdgcn_readfirstlane(seen);
+        prog[wave] = P;
+        seen = prog[partner];
+        if (theirs < P - 1) __builtin_amdgcn_s_setprio(0);
+        else if (theirs > P) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
+      }
+    } else if (VAR & 2) {
+      if (exchange) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(1);
+    }
+  };
   double *buf = reinterpret_cast<double *>(smem) + wave * EV3_SLOTS;
   const int mean = st.mean;
   const double rcp = st.rcp, rcp_lo = st.rcp_lo;
@@ -927,13 +1054,30 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     preh = p[min(1024 * rho_ + 256 * g + l, n_used - 1)];
   };
   fetch(r0);
+  double held[8]; /* VAR bit 3: mir[] of the previous round */
+#pragma unroll
+  for (int k0 = 0; k0 < 8; ++k0) held[k0] = 0.0;
+  /* VAR bit 3: a publication that carries nothing but the second halves of the round before */
+  auto publish_held_only = [&]() {
+    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
+    ev_lds_acquire();
+    double *tg = terms + (4 * wave + g) * EV_TROW;
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0)
+      if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0];
+    ev_wave_sync(); /* no wait: see the publication at the end of a round */
+  };
   for (int s = 0; s < steps; ++s) {
     ++seq;
     const int rho = r0 + s;
     if (rho >= r1) { /* this wave's run is one round shorter than its neighbours': nothing to hand over */
+      if (VAR & 8) publish_held_only();
       if (ln == 0) flags[wave] = seq;
+      if (VAR & 1) prog[wave] = 6 * seq + 12;
       continue;
     }
+    stamp(s, 0);
+    phase(0, false);
     /* 1. normalise (ref :109-114) the 32 samples into registers */
     double yv[16], yh;
     {
@@ -997,6 +1141,8 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     const int xa = base5 + g, xb = xa + 1;
     const int pa = xa >= 5 ? xa - 5 : xa, pb = xb >= 5 ? xb - 5 : xb;
     double *blk_a = buf + pa * EV3_BLK, *blk_b = buf + pb * EV3_BLK;
+    stamp(s, 1);
+    phase(1, true);
     ev_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
 #pragma unroll
     for (int i = 0; i < 16; ++i) blk_b[18 * l + i] = yv[i];
@@ -1016,12 +1162,16 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
       for (int m1 = 8; m1 < 16; ++m1) { re[m1] = ib[36 * (m1 - 8)]; im[m1] = ib[36 * (m1 - 8) + 1]; }
     }
     ev_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
+    stamp(s, 2);
+    phase(2, false);
     bl_fft16(re, im);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
       const c2d w = k1 < EV3_W1_REGS ? w1r[k1] : tw256[k1 * 16 + l];
       bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w.re, w.im);
     }
+    stamp(s, 3);
+    phase(3, true);
     double *xg = blk_a; /* [16][18] doubles, re then im */
     const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
 #pragma unroll
@@ -1036,6 +1186,8 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
     ev_wave_sync();
+    stamp(s, 4);
+    phase(4, false);
     bl_fft16(re, im);
     /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16 —
      * a mirror of the 16-lane row followed by a rotation by one, two DPP moves per dword and no LDS
@@ -1055,19 +1207,44 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     }
     const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
     const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
+    stamp(s, 5);
+    phase(5, true);
+    double *tg = terms + (4 * wave + g) * EV_TROW;
+    /* the rows are free once the summing wave has taken tile seq - 1 out of them */
     while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
     ev_lds_acquire();
-    double *tg = terms + (4 * wave + g) * EV_TROW;
+    stamp(s, 6);
+    if (VAR & 8) {
+      /* terms 0..129 of this round (term 129 is lane 15's mir[7]) and terms 130..256 of the round before */
 #pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) {
-      tg[l + 16 * k0] = own[k0];
-      tg[256 - l - 16 * k0] = mir[k0];
+      for (int k0 = 0; k0 < 8; ++k0) {
+        tg[l + 16 * k0] = own[k0];
+        if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0];
+        held[k0] = mir[k0];
+      }
+      if (l == 0) tg[128] = mid;
+      if (l == 15) tg[129] = mir[7];
+    } else {
+#pragma unroll
+      for (int k0 = 0; k0 < 8; ++k0) {
+        tg[l + 16 * k0] = own[k0];
+        tg[256 - l - 16 * k0] = mir[k0];
+      }
+      if (l == 0) tg[128] = mid;
     }
-    if (l == 0) tg[128] = mid;
-    ev_lds_release();
+    /* The LDS executes one wave's instructions in order: the sequence word below lands after the terms above
+     * whether this wave waits for them or not, and nothing in the next round needs them.  Bit 3 does not wait
+     * (~1 k cycles of LDS queue per round, with no arithmetic to cover them). */
+    if (!(VAR & 8)) ev_lds_release();
     ev_wave_sync();
     if (ln == 0) flags[wave] = seq;
+    stamp(s, 7);
     base5 = base5 == 0 ? 4 : base5 - 1; /* (4 (rho + 1)) mod 5 */
+  }
+  if (VAR & 8) { /* the second halves of the last round: one more publication, nothing else in it */
+    ++seq;
+    publish_held_only();
+    if (ln == 0) flags[wave] = seq;
   }
 }
 #undef FC
@@ -1500,12 +1677,19 @@ bl_tables blk_tables_bind(const void *d_mem) {
 }
 
 int blk_configure_device(void) {
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows3<0, BL_ENV_VARIANT>),
+                         reinterpret_cast<const void *>(k_env_windows3<1, BL_ENV_VARIANT>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_VARIANT>)})
+    BL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+#ifdef BL_AMD_MEASURE
+  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows3<2, 0>), reinterpret_cast<const void *>(k_env_windows3<2, 1>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, 2>), reinterpret_cast<const void *>(k_env_windows3<2, 4>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, 5>), reinterpret_cast<const void *>(k_env_windows3<2, 6>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, 8>), reinterpret_cast<const void *>(k_env_windows3<2, 9>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, 10>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, 12>), reinterpret_cast<const void *>(k_env_windows3<2, 13>)})
+    BL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+#endif
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
   return BL_OK;
@@ -1527,6 +1711,18 @@ struct Mark {
 };
 
 } // namespace
+
+static long long *g_env_probe = nullptr;
+#ifdef BL_AMD_MEASURE
+/* measurement builds only: pick a scheduling variant at run time (-1: the compiled default) and give the probe
+ * instantiations (bit 2) a device buffer of 8 x EV_PROBE_ROUNDS x EV_PROBE_SLOTS int64 for their s_memtime stamps */
+static int g_env_variant = -1;
+extern "C" __attribute__((visibility("default"))) int bl_amd_measure_env(int variant, void *d_probe) {
+  g_env_variant = variant;
+  g_env_probe = static_cast<long long *>(d_probe);
+  return BL_OK;
+}
+#endif
 
 /* Which form of the 17-tap FIR k_env_windows3 runs:
  *   0  the reference's unfused order (BL_FIR) — bit-identical window energies;
@@ -1612,15 +1808,30 @@ int blk_analyze(const blk_analyze_args &a) {
        * block a run filters before its first round stays a small part of it */
       const int gx2 = grid_x_for(std::max(1, (2 * max_frames) / (4 * 4 * EV_CWAVES)), n_songs, 2, a.n_cu);
       const int fir_mode = blk_fir_mode();
-      if (fir_mode == 2)
-        hipLaunchKernelGGL(k_env_windows3<2>, dim3(gx2, n_songs), dim3(64 * (EV_CWAVES + 1)),
-                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
-      else if (fir_mode == 1)
-        hipLaunchKernelGGL(k_env_windows3<1>, dim3(gx2, n_songs), dim3(64 * (EV_CWAVES + 1)),
-                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
-      else
-        hipLaunchKernelGGL(k_env_windows3<0>, dim3(gx2, n_songs), dim3(64 * (EV_CWAVES + 1)),
-                           EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, a.energies, a.lc);
+      const dim3 grid(gx2, n_songs), block(64 * (EV_CWAVES + 1));
+#define EV_LAUNCH(M, V)                                                                              \
+  hipLaunchKernelGGL((k_env_windows3<M, V>), grid, block, EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, \
+                     a.energies, a.lc, g_env_probe)
+#ifdef BL_AMD_MEASURE
+      const int var = g_env_variant;
+      if (fir_mode == 2 && var >= 0 && var != BL_ENV_VARIANT) { /* bl_amd_measure_env(): A/B of the scheduling variants */
+        if (var == 0) EV_LAUNCH(2, 0);
+        else if (var == 1) EV_LAUNCH(2, 1);
+        else if (var == 2) EV_LAUNCH(2, 2);
+        else if (var == 4) EV_LAUNCH(2, 4);
+        else if (var == 5) EV_LAUNCH(2, 5);
+        else if (var == 6) EV_LAUNCH(2, 6);
+        else if (var == 8) EV_LAUNCH(2, 8);
+        else if (var == 9) EV_LAUNCH(2, 9);
+        else if (var == 10) EV_LAUNCH(2, 10);
+        else if (var == 12) EV_LAUNCH(2, 12);
+        else EV_LAUNCH(2, 13);
+      } else
+#endif
+      if (fir_mode == 2) EV_LAUNCH(2, BL_ENV_VARIANT);
+      else if (fir_mode == 1) EV_LAUNCH(1, BL_ENV_VARIANT);
+      else EV_LAUNCH(0, BL_ENV_VARIANT);
+#undef EV_LAUNCH
     }
     hipStream_t ts = stream;
     if ((what & 3) && a.side) { /* something to overlap with */
