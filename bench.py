@@ -64,7 +64,7 @@ def _cpu_limits():
     return info
 
 
-def cpu_baseline():
+def cpu_baseline(ladder_levels=(1, 8, 32, 64, 128, 256)):
     """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of
     the same workload.  One process per worker (not threads: the reference is not thread
     re-entrant — FFTW planner globals, ref src/tempo_atk_sort.c:94,294-295), each analysing
@@ -98,11 +98,11 @@ def cpu_baseline():
 
     ladder = [level(1, 2, 9000)]
     one = ladder[0]["songs_per_s"]
-    for procs in (8, 32, 64, 128, 256):
+    for procs in [p for p in ladder_levels if p > 1]:
         if procs > max(avail, 1):
             break
         ladder.append(level(procs, 1, 9100 + procs))
-    if ladder[-1]["processes"] != avail and avail > 1 and avail not in (8, 32, 64, 128, 256):
+    if ladder[-1]["processes"] != avail and avail > 1 and avail not in ladder_levels and len(ladder_levels) > 2:
         ladder.append(level(avail, 1, 9700))
     best = max(l["songs_per_s"] for l in ladder)
     eff = next(l["processes"] for l in ladder if l["songs_per_s"] >= 0.9 * best)
@@ -279,6 +279,11 @@ def plumbing_only(args):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ok = bool(np.array_equal(allv.numpy(), np.stack([vec(i) for i in range(total)])))
+    per_rank = torch.tensor([[1e3 * elapsed / max(args.steps + args.warmup, 1)]], dtype=torch.float64)
+    if dist.is_initialized():
+        gathered = torch.empty((world, 1), dtype=torch.float64)
+        dist.all_gather_into_tensor(gathered, per_rank)
+        per_rank = gathered
     if rank == 0:
         print(json.dumps({"metric": "plumbing-only (no analysis, stand-in vectors)", "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -288,6 +293,8 @@ def plumbing_only(args):
                           "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                                          "all_gather_calls": gathers if dist.is_initialized() else 0,
                                          "bytes_per_rank": 16 * songs},
+                          "per_rank": {"ms_per_step": [float(x) for x in per_rank[:, 0]],
+                                       "ms_per_step_min": float(per_rank.min()), "ms_per_step_max": float(per_rank.max())},
                           "results_ok": ok}), flush=True)
     if dist.is_initialized():
         dist.barrier()
@@ -304,6 +311,8 @@ def main():
                     help="0 = configs[2] shard (8192) if it fits in HBM, else the largest count that does")
     ap.add_argument("--seconds", type=int, default=SONG_SECONDS, help="song length (default 180)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ladder", default="1,8,32,64,128,256",
+                    help="concurrent oracle processes per rung of the CPU baseline (tests shorten it)")
     ap.add_argument("--verify", type=int, default=32,
                     help="songs of the resident batch re-analysed by the CPU oracle after the timed region")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -348,11 +357,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     # where the tensors of the collectives live: on the GPU for RCCL, in host memory for the gloo rehearsal
     cdev = torch.device("cpu") if args.share_device else dev
+    side = None   # a gloo group beside the RCCL one: the ranks park in its barrier (a blocked socket, no spinning
+                  # host thread) while rank 0 times the CPU baseline on the host cores they share
     if world > 1 or (under_launcher and "MASTER_ADDR" in os.environ):  # torchrun: RCCL group even at world size 1
+        import datetime
         if args.share_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        side = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
 
     import bliss_amd
     from bliss_amd import _lib
@@ -424,6 +437,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.bl_amd_profile(0)
+    my_elapsed = elapsed
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -437,6 +451,15 @@ def main():
         ms = lib.bl_amd_profile_ms(name.encode(), C.byref(n))
         kern[name] = {"ms_total": ms, "launches": n.value,
                       "ms_avg": (ms / n.value) if n.value else None}
+
+    # every rank's own clock and its dominant kernel, so that a scaling loss can be put on a slow rank (a gather of
+    # two doubles per rank) rather than on the collective
+    mine2 = torch.tensor([1e3 * my_elapsed / args.steps, kern["env_windows"]["ms_avg"] or 0.0], dtype=torch.float64, device=cdev)
+    per_rank = mine2.unsqueeze(0)
+    if dist.is_initialized():
+        per_rank = torch.empty((world, 2), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(per_rank, mine2.unsqueeze(0))
+    per_rank = per_rank.cpu().numpy()
 
     res = corpus.fetch()
     ok = bool(np.all(res["status"] == 0) and np.all(np.isfinite(res["force"])))
@@ -585,17 +608,30 @@ def main():
             "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                            "all_gather_calls": n_gathers[0] if dist.is_initialized() else 0,
                            "bytes_per_rank": 16 * songs},
+            "per_rank": {"ms_per_step": [float(x) for x in per_rank[:, 0]],
+                         "ms_per_step_min": float(per_rank[:, 0].min()), "ms_per_step_max": float(per_rank[:, 0].max()),
+                         "env_windows_ms": [float(x) for x in per_rank[:, 1]],
+                         "what": "each rank's own wall clock over the timed steps (the line's ms_per_step is the max) "
+                                 "and its k_env_windows3 HIP-event average"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        # the CPU baseline runs on rank 0 at every N (after the timed region and every reduction; the other
+        # ranks wait in a gloo barrier, which blocks on a socket instead of spinning)
+        if args.no_cpu_baseline:
+            line["cpu_baseline"] = {"value": None, "unit": "songs/s", "cores": None, "kind": "port",
+                                    "sample": "not measured in this run (--no-cpu-baseline): see the N = 1 line of the "
+                                              "same box, BENCH_r*.json"}
+        else:
             try:
-                line["cpu_baseline"] = cpu_baseline()
+                line["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in args.cpu_ladder.split(",")))
+                if world > 1:
+                    line["cpu_baseline"]["sample"] += f"; timed on rank 0 of {world} after the timed region, the other ranks parked"
             except Exception as e:  # the baseline must never sink the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "songs/s", "cores": None,
                                         "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(group=side)
         dist.destroy_process_group()
 
 

@@ -119,6 +119,29 @@ def test_bench_self_launch_plumbing():
     assert line["n_gpus"] == 2 and line["results_ok"] is True
     assert line["collective"] == {"backend": "gloo", "all_gather_calls": 3, "bytes_per_rank": 80}
     assert line["config"]["parallelism"] == "shard2"
+    assert len(line["per_rank"]["ms_per_step"]) == 2
+
+
+def test_bench_plumbing_at_the_world_size_of_configs2():
+    """The 8-rank job of BASELINE configs[2], as far as a box without GPUs can run it: `bench.py --gpus 8
+    --plumbing-only` starts its own eight ranks, the gloo group forms, every rank contributes its shard and rank 0
+    prints one line with the eight ranks' own clocks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--plumbing-only", "--songs-per-gpu", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["results_ok"] is True
+    assert line["collective"] == {"backend": "gloo", "all_gather_calls": 3, "bytes_per_rank": 48}
+    assert line["config"]["parallelism"] == "shard8" and "24 total" in line["config"]["workload"]
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and pr["ms_per_step_min"] <= pr["ms_per_step_max"]
 
 
 def test_bench_refuses_more_gpus_than_devices():

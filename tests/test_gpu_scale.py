@@ -171,7 +171,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu_lib):
     the ranks' shards and seeds (rank 1 analyses songs 24..47), the gather order, row blocks that
     start at row 24, the oracle check shared out over the ranks, results_ok reduced over both."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "1",
-           "--songs-per-gpu", "24", "--seconds", "20", "--no-cpu-baseline", "--verify", "8"]
+           "--songs-per-gpu", "24", "--seconds", "20", "--cpu-ladder", "1,8", "--verify", "8"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -181,3 +181,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu_lib):
     assert line["collective"]["backend"] == "gloo" and line["collective"]["all_gather_calls"] >= 2
     assert line["config"]["songs_per_gpu"] == 24 and line["config"]["parallelism"] == "shard2"
     assert "48 songs total" in line["config"]["workload"] and line["rehearsal"]
+    # an N > 1 line carries what a scaling run needs to be read: the CPU baseline (rank 0, after the timed region)
+    # and every rank's own clock and dominant-kernel time
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port" and "rank 0 of 2" in line["cpu_baseline"]["sample"]
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 == len(pr["env_windows_ms"]) and min(pr["env_windows_ms"]) > 0
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= line["ms_per_step"] * 1.001
