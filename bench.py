@@ -160,14 +160,16 @@ def verify_songs(res, picks, seed_first, seconds):
         g = res[i]
         bad = [k for k in ("start", "end", "mean", "variance", "n_frames", "nb_frames", "n_windows", "beat",
                            "calm_or_loud") if int(g[k]) != int(ref[k])]
-        worst = 0.0
+        worst, by_field = 0.0, {}
         for k in ("tempo", "amplitude", "frequency", "attack", "force"):
             a, b = float(g[k]), float(ref[k])
             rel = abs(a - b) / max(abs(b), 1e-6)
             worst = max(worst, rel)
+            by_field[k] = rel
             if not rel <= 1e-4:
                 bad.append(k)
-        details.append({"song": int(i), "beat": int(g["beat"]), "max_rel_err": worst, "mismatch": bad})
+        details.append({"song": int(i), "beat": int(g["beat"]), "max_rel_err": worst, "rel_err_by_field": by_field,
+                        "mismatch": bad})
         ok = ok and not bad
     return ok, details
 
@@ -599,6 +601,8 @@ def main():
                                         "checks its share of --verify (results_ok / verified_songs are reduced over the "
                                         "ranks, the list below is rank 0's)",
                              "bar": "integers identical, f32 features <= 1e-4 relative",
+                             "worst_rel_err_by_field": {k: max((d["rel_err_by_field"][k] for d in verify_details), default=None)
+                                                        for k in ("tempo", "amplitude", "frequency", "attack", "force")},
                              "songs": verify_details},
             "memory": {"free_bytes_before_alloc": int(free_b), "total_bytes": int(total_b),
                        "free_bytes_after_alloc": int(mem_after_alloc[0]),

@@ -116,6 +116,7 @@ SYMBOLS = {
     "bl_amd_distance_matrix_host": (C.c_int, [_P(ForceVector), C.c_int, _P(C.c_float)]),
     "bl_amd_cosine_matrix_host": (C.c_int, [_P(ForceVector), C.c_int, _P(C.c_float)]),
     "bl_amd_selftest_sqrt": (C.c_int, [_P(C.c_uint64)]),
+    "bl_amd_selftest_cos": (C.c_int, [_P(C.c_uint64), C.c_uint64]),
     "bl_amd_playlist_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bl_amd_playlist_host": (C.c_int, [_P(ForceVector), C.c_int, C.c_int, _P(C.c_int32), _P(C.c_float)]),
     "bl_amd_synth_pcm_device": (C.c_int, [C.c_void_p, _P(SongDesc), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]),

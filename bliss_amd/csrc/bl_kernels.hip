@@ -34,6 +34,7 @@
 #include <string.h>
 
 #include "bl_launch.h"
+#include "bl_cos.h"
 #include "bl_sqrt.h"
 #include "bl_tail.h"
 
@@ -1434,12 +1435,9 @@ __device__ __forceinline__ float bl_dist(const float4 a, const float4 b) {
   return sqrtf(bl_dist_sq(a, b));
 }
 
-__device__ __forceinline__ float bl_cos(const float4 a, const float4 b) {
-  /* ref analyze.c:135-140: f32 dot / norms, double sqrt, product and divide */
-  const float dot = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-  const float na = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-  const float nb = b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
-  return (float)((double)dot / (sqrt((double)na) * sqrt((double)nb)));
+/* ref analyze.c:135-140: the f32 dot product, left to right */
+__device__ __forceinline__ float bl_dot(const float4 a, const float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
 
 /* A workgroup owns BL_PW_ROWS rows x 1024 columns: every thread keeps its four column
@@ -1456,12 +1454,28 @@ __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vec
                                                   int row_begin, int n_rows,
                                                   float *__restrict__ out) {
   const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int r0 = blockIdx.y * BL_PW_ROWS;
+  const int r1 = min(r0 + BL_PW_ROWS, n_rows);
+  /* cosine: what depends on one vector only — squared norm, its double root, the root's reciprocal (bl_cos.h) —
+   * once per row of the workgroup (LDS) and once per column of the thread, not once per output */
+  __shared__ double row_s[COSINE ? BL_PW_ROWS : 1], row_r[COSINE ? BL_PW_ROWS : 1];
+  if (COSINE) {
+    if ((int)threadIdx.x < r1 - r0) {
+      const bl_cos_vec p = bl_cos_prep(vecs[row_begin + r0 + threadIdx.x]);
+      row_s[threadIdx.x] = p.s;
+      row_r[threadIdx.x] = p.r;
+    }
+    __syncthreads();
+  }
   if (j0 >= n) return;
   float4 b[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) b[k] = vecs[min(j0 + k, n - 1)];
-  const int r0 = blockIdx.y * BL_PW_ROWS;
-  const int r1 = min(r0 + BL_PW_ROWS, n_rows);
+  bl_cos_vec cb[COSINE ? 4 : 1];
+  if (COSINE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cb[k] = bl_cos_prep(b[k]);
+  }
   const bool vec_ok = j0 + 4 <= n && (n & 3) == 0 && ((reinterpret_cast<size_t>(out) & 15) == 0);
   for (int row = r0; row < r1; ++row) {
     const float4 a = vecs[row_begin + row];
@@ -1471,8 +1485,22 @@ __global__ __launch_bounds__(256) void k_pairwise(const float4 *__restrict__ vec
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[k] = a.x;
     } else if (COSINE) {
+      /* q' = dot * (ra * rb) where its float is provably the reference's (bl_cos.h); a wave with any output
+       * near a float rounding boundary, a zero dot product or a degenerate norm takes the plain expression */
+      const double ra = row_r[row - r0];
+      float dot[4];
+      bool fast = true;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) r[k] = bl_cos(a, b[k]);
+      for (int k = 0; k < 4; ++k) {
+        dot[k] = bl_dot(a, b[k]);
+        fast = bl_cos_fast(dot[k], ra * cb[k].r, r[k]) && fast;
+      }
+      if (!__all(fast)) {
+        bl_cos_vec ca;
+        ca.s = row_s[row - r0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = bl_cos_plain(dot[k], ca, cb[k]);
+      }
     } else {
       /* the five-instruction root where every sum of the wave is in its domain (bl_sqrt.h), the
        * compiler's sqrtf otherwise: a zero (the diagonal, duplicate songs), a tiny or a non-finite
@@ -1780,7 +1808,6 @@ int grid_x_for(long long units_max, int n_songs, int blocks_per_cu, int n_cu) {
 int blk_analyze(const blk_analyze_args &a) {
   const int n_songs = a.n_songs, what = a.what;
   hipStream_t stream = a.stream;
-  const int max_frames = a.max_n / 512;
   const int gx_scan = grid_x_for(((long long)a.max_n / 8 + 255) / 256, n_songs, 8, a.n_cu);
   BL_HIP_CHECK(hipMemsetAsync(a.hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
   const int tb64 = (n_songs + 63) / 64;
@@ -1801,17 +1828,17 @@ int blk_analyze(const blk_analyze_args &a) {
    * latency-bound wave per 64 songs and leaves the chip free); k_force joins the two. */
   bool tail_async = false;
   if (what & 4) {
-    {
+    const int fir_mode = blk_fir_mode();
+    /* one 512-thread workgroup per CU; the blocks of a song split its rounds of four windows
+     * into contiguous runs, one per compute wave: at least four rounds per run, so that the
+     * block a run filters before its first round stays a small part of it */
+    auto launch_env = [&](int first, int count, int maxn) {
       Mark m(a.mark, a.mark_user, PK_ENV, stream);
-      /* one 512-thread workgroup per CU; the blocks of a song split its rounds of four windows
-       * into contiguous runs, one per compute wave: at least four rounds per run, so that the
-       * block a run filters before its first round stays a small part of it */
-      const int gx2 = grid_x_for(std::max(1, (2 * max_frames) / (4 * 4 * EV_CWAVES)), n_songs, 2, a.n_cu);
-      const int fir_mode = blk_fir_mode();
-      const dim3 grid(gx2, n_songs), block(64 * (EV_CWAVES + 1));
+      const int gx2 = grid_x_for(std::max(1, (2 * (maxn / 512)) / (4 * 4 * EV_CWAVES)), count, 2, a.n_cu);
+      const dim3 grid(gx2, count), block(64 * (EV_CWAVES + 1));
 #define EV_LAUNCH(M, V)                                                                              \
-  hipLaunchKernelGGL((k_env_windows3<M, V>), grid, block, EV3_LDS_BYTES, stream, a.pcm, a.songs, a.stats, a.tb, \
-                     a.energies, a.lc, g_env_probe)
+  hipLaunchKernelGGL((k_env_windows3<M, V>), grid, block, EV3_LDS_BYTES, stream, a.pcm, a.songs + first, \
+                     a.stats + first, a.tb, a.energies, a.lc, g_env_probe)
 #ifdef BL_AMD_MEASURE
       const int var = g_env_variant;
       if (fir_mode == 2 && var >= 0 && var != BL_ENV_VARIANT) { /* bl_amd_measure_env(): A/B of the scheduling variants */
@@ -1832,18 +1859,36 @@ int blk_analyze(const blk_analyze_args &a) {
       else if (fir_mode == 1) EV_LAUNCH(1, BL_ENV_VARIANT);
       else EV_LAUNCH(0, BL_ENV_VARIANT);
 #undef EV_LAUNCH
-    }
-    hipStream_t ts = stream;
-    if ((what & 3) && a.side) { /* something to overlap with */
-      BL_HIP_CHECK(hipEventRecord(a.ev_env, stream));
-      BL_HIP_CHECK(hipStreamWaitEvent(a.side, a.ev_env, 0));
-      ts = a.side;
-      tail_async = true;
-    }
-    {
+    };
+    /* the serial tail of the songs [first, first + count), on the side stream when there is something to
+     * overlap it with */
+    const bool side = (what & 3) && a.side;
+    auto launch_tail = [&](int first, int count) -> int {
+      hipStream_t ts = stream;
+      if (side) {
+        BL_HIP_CHECK(hipEventRecord(a.ev_env, stream));
+        BL_HIP_CHECK(hipStreamWaitEvent(a.side, a.ev_env, 0));
+        ts = a.side;
+        tail_async = true;
+      }
       Mark m(a.mark, a.mark_user, PK_TAIL, ts);
-      hipLaunchKernelGGL(k_env_tail, dim3(tb64), dim3(192), 0, ts, a.songs, a.lc, n_songs, a.results,
-                         what);
+      hipLaunchKernelGGL(k_env_tail, dim3((count + 63) / 64), dim3(192), 0, ts, a.songs + first, a.lc, count,
+                         a.results, what);
+      return BL_OK;
+    };
+    /* Mixed lengths (records sorted longest first): the tail of a ten-minute song is a ~15 ms serial chain, and
+     * launched behind the window kernel of the whole batch it outlasts the frequency pass it is meant to hide
+     * behind.  The long songs [0, n_head) get their own window launch, and their tail runs on the side stream
+     * under the window kernel of the rest. */
+    const int n_head = (a.n_head > 0 && a.n_head < n_songs && side) ? a.n_head : 0;
+    if (n_head) {
+      launch_env(0, n_head, a.max_n);
+      if (launch_tail(0, n_head) != BL_OK) return BL_UNEXPECTED;
+      launch_env(n_head, n_songs - n_head, a.max_n_rest);
+      if (launch_tail(n_head, n_songs - n_head) != BL_OK) return BL_UNEXPECTED;
+    } else {
+      launch_env(0, n_songs, a.max_n);
+      if (launch_tail(0, n_songs) != BL_OK) return BL_UNEXPECTED;
     }
     if (tail_async) BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
   }
@@ -1911,6 +1956,73 @@ int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int 
                          row_begin + r0, cnt, d_out + (size_t)r0 * n);
 #endif
   }
+  BL_HIP_CHECK(hipGetLastError());
+  return BL_OK;
+}
+
+/* Sweep of bl_cos_fast against the plain expression over pseudo-random (dot, na, nb): norms over 2^-40..2^40
+ * (a quarter of them within 2^-4..2^16, where force vectors live), dot = u * sqrt(na nb) with u in [-1, 1], and for
+ * each such triple the 8 neighbouring floats of dot.  counts: [0] triples, [1] triples the fast path accepts,
+ * [2] accepted triples whose float differs from the plain expression's (must be 0), [3] largest |q' - q| seen,
+ * in ulp of the double quotient (bound: 3.5), [4] triples whose q lies within 64 ulp of a float rounding
+ * boundary, [5] of those, how many the unguarded (float)q' would get wrong. */
+__global__ __launch_bounds__(256) void k_cos_sweep(unsigned long long seed, int per_thread, unsigned long long *counts) {
+  unsigned long long st = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * 256ull + threadIdx.x + 1);
+  auto next = [&]() -> unsigned {
+    st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+    return (unsigned)(st >> 32) ^ (unsigned)st;
+  };
+  auto rnd_norm = [&]() -> float {
+    const unsigned r = next();
+    const int span = (r & 3u) ? 80 : 20, base = (r & 3u) ? -40 : -4;
+    const int e = base + (int)((r >> 2) % (unsigned)span);
+    return ldexpf(1.0f + (float)(next() >> 9) * (1.0f / 8388608.0f), e);
+  };
+  unsigned long long n = 0, n_fast = 0, bad = 0, max_ulp = 0, near = 0, near_bad = 0;
+  for (int it = 0; it < per_thread; ++it) {
+    bl_cos_vec a, b;
+    a.n = rnd_norm(); b.n = rnd_norm();
+    a.s = sqrt((double)a.n); a.r = 1.0 / a.s;
+    b.s = sqrt((double)b.n); b.r = 1.0 / b.s;
+    const float u = (float)((int)next()) * (1.0f / 2147483648.0f);
+    const float d0 = (float)((double)u * (a.s * b.s));
+    for (int j = -4; j < 4; ++j) {
+      const float dot = __uint_as_float(__float_as_uint(d0) + (unsigned)j);
+      const float want = bl_cos_plain(dot, a, b);
+      float got;
+      const bool ok = bl_cos_fast(dot, a.r * b.r, got);
+      const double q = (double)dot / (a.s * b.s), qf = (double)dot * (a.r * b.r);
+      const long long bq = __double_as_longlong(q), bf = __double_as_longlong(qf);
+      ++n;
+      if (ok) {
+        ++n_fast;
+        if (__float_as_uint(got) != __float_as_uint(want)) ++bad;
+      }
+      if (q == q && qf == qf && q != 0.0 && (bq >> 63) == (bf >> 63)) {
+        const unsigned long long d = (unsigned long long)(bq > bf ? bq - bf : bf - bq);
+        if (d < (1ull << 40)) max_ulp = max(max_ulp, d);
+        const unsigned lo = (unsigned)bq & 0x1FFFFFFFu;
+        if (lo - (0x10000000u - 64u) <= 128u) {
+          ++near;
+          if (__float_as_uint(got) != __float_as_uint(want)) ++near_bad;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n += __shfl_down(n, off); n_fast += __shfl_down(n_fast, off); bad += __shfl_down(bad, off);
+    near += __shfl_down(near, off); near_bad += __shfl_down(near_bad, off);
+    max_ulp = max(max_ulp, (unsigned long long)__shfl_down(max_ulp, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], n); atomicAdd(&counts[1], n_fast); atomicAdd(&counts[2], bad);
+    atomicMax(&counts[3], max_ulp); atomicAdd(&counts[4], near); atomicAdd(&counts[5], near_bad);
+  }
+}
+
+int blk_cos_sweep(hipStream_t s, unsigned long long seed, int per_thread, unsigned long long *d_counts, int n_cu) {
+  hipLaunchKernelGGL(k_cos_sweep, dim3(n_cu * 8), dim3(256), 0, s, seed, per_thread, d_counts);
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }

@@ -80,6 +80,7 @@ struct blk_analyze_args {
   double *lc;                /* device scratch, one per envelope slot */
   bl_amd_song_result *results;
   int n_songs, max_n, what, n_cu;
+  int n_head = 0, max_n_rest = 0; /* mixed lengths: the first n_head (longest) songs get their own window launch */
   bl_tables tb;
   hipStream_t stream, side;  /* side == nullptr: envelope tail on `stream` */
   hipEvent_t ev_env, ev_tail;
@@ -96,6 +97,7 @@ int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int 
  * values in the fast domain, mismatches of the fast root, mismatches of the compiler's sqrtf */
 int blk_sqrt_sweep(hipStream_t s, unsigned long long first, unsigned long long count,
                    unsigned long long *d_counts, int n_cu);
+int blk_cos_sweep(hipStream_t s, unsigned long long seed, int per_thread, unsigned long long *d_counts, int n_cu);
 int blk_playlist(hipStream_t s, const struct force_vector_s *d_vecs, int n, int seed_index,
                  int32_t *d_order, float *d_dist);
 /* out[i] = (int16)(in[i] >> 16): the same-rate S32 -> S16 narrowing */

@@ -327,6 +327,17 @@ int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_de
     a.results = d_results + b;
     a.n_songs = cnt;
     a.max_n = max_n[gi];
+    /* a mixed-length group (sorted longest first by fill_group): the songs longer than a quarter of the longest
+     * go first, in whole waves of the tail kernel, if both parts stay wide enough to fill the chip */
+    if (cnt >= 1024 && hs[b].n != hs[b + cnt - 1].n) {
+      int k = 0;
+      while (k < cnt && hs[b + k].n > max_n[gi] / 4) ++k;
+      k = (k + 63) / 64 * 64;
+      if (k >= 256 && k <= cnt - 256) {
+        a.n_head = k;
+        a.max_n_rest = hs[b + k].n;
+      }
+    }
     a.what = what;
     a.n_cu = c->n_cu;
     a.tb = c->tb;
@@ -851,6 +862,27 @@ int bl_amd_selftest_sqrt(uint64_t counts[3]) {
       blk_sqrt_sweep(nullptr, 0ull, 1ull << 32, d, c->n_cu) == BL_OK &&   /* every f32 bit pattern */
       hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
     for (int k = 0; k < 3; ++k) counts[k] = h[k];
+    rc = BL_OK;
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+int bl_amd_selftest_cos(uint64_t counts[6], uint64_t triples) {
+  if (!counts) return BL_UNEXPECTED;
+  bl_amd_ctx *c = blr_default_ctx();
+  if (!c) return BL_UNEXPECTED;
+  DevGuard dg(c->device);
+  unsigned long long *d = nullptr;
+  BL_HIP_CHECK(hipMalloc(&d, 6 * sizeof(unsigned long long)));
+  int rc = BL_UNEXPECTED;
+  unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long threads = (unsigned long long)c->n_cu * 8 * 256;
+  const int per_thread = (int)std::min<unsigned long long>((triples / 8 + threads - 1) / threads, 1u << 24);
+  if (hipMemset(d, 0, sizeof h) == hipSuccess &&
+      blk_cos_sweep(nullptr, 0x5eedc05ull, std::max(per_thread, 1), d, c->n_cu) == BL_OK &&
+      hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+    for (int k = 0; k < 6; ++k) counts[k] = h[k];
     rc = BL_OK;
   }
   (void)hipFree(d);

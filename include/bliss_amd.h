@@ -242,6 +242,12 @@ int bl_amd_cosine_matrix_host(const struct force_vector_s *h_vecs, int n, float 
  * counts[1] = its mismatches, counts[2] = mismatches of the fallback (the compiler's correctly
  * rounded sqrtf) over all 2^32 patterns.  Both must be 0 (tests/test_gpu_parity.py). */
 int bl_amd_selftest_sqrt(uint64_t counts[3]);
+/* Same for the cosine matrix's guarded quotient (bl_cos.h): at least `triples` pseudo-random (dot, |a|^2, |b|^2)
+ * on the device against the plain expression of ref src/analyze.c:135-140.  counts: [0] triples tried, [1] taken by
+ * the fast path, [2] fast results that differ from the plain expression (must be 0), [3] largest difference of
+ * the two double quotients in ulp (bound 3.5, guard 16), [4] triples within 64 ulp of a float rounding boundary,
+ * [5] of those, how many an unguarded fast path would have got wrong. */
+int bl_amd_selftest_cos(uint64_t counts[6], uint64_t triples);
 
 /* Seeded playlist (ref python/examples/make_m3u_playlist.py:62-72): d_dist[j] =
  * bl_distance(vecs[seed_index], vecs[j]) and d_order = the song indices by increasing

@@ -291,6 +291,13 @@ float orc_cosine(const float a[4], const float b[4]) {
   return (float)(dot / (sqrt(na) * sqrt(nb)));
 }
 
+/* the all-pairs form of the same expression, for the kernels' matrix (test infrastructure, as everything here) */
+void orc_cosine_matrix(const float *vecs, int n, float *out) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      out[(size_t)i * n + j] = orc_cosine(vecs + 4 * i, vecs + 4 * j);
+}
+
 void orc_distance_matrix(const float *vecs, int n, float *out) {
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j)

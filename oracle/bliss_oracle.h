@@ -58,6 +58,7 @@ int orc_analyze_pcm(const int16_t *pcm, int n, int channels, uint64_t duration,
 float orc_distance(const float a[4], const float b[4]);
 float orc_cosine(const float a[4], const float b[4]);
 void orc_distance_matrix(const float *vecs, int n, float *out);
+void orc_cosine_matrix(const float *vecs, int n, float *out);
 
 /* FFTs (orc_fft.c) */
 void orc_rdft512_f32(float *x);                 /* in-place, FFmpeg packed layout */

@@ -58,6 +58,8 @@ class Oracle:
         L.orc_cosine.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_distance_matrix.restype = None
         L.orc_distance_matrix.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
+        L.orc_cosine_matrix.restype = None
+        L.orc_cosine_matrix.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
         L.orc_synth_fill.restype = None
         L.orc_synth_fill.argtypes = [i16p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
 
@@ -104,6 +106,13 @@ class Oracle:
         out = np.empty((v.shape[0], v.shape[0]), dtype=np.float32)
         fp = C.POINTER(C.c_float)
         self.lib.orc_distance_matrix(v.ctypes.data_as(fp), v.shape[0], out.ctypes.data_as(fp))
+        return out
+
+    def cosine_matrix(self, vecs):
+        v = np.ascontiguousarray(vecs, dtype=np.float32).reshape(-1, 4)
+        out = np.empty((v.shape[0], v.shape[0]), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        self.lib.orc_cosine_matrix(v.ctypes.data_as(fp), v.shape[0], out.ctypes.data_as(fp))
         return out
 
     def cosine(self, a, b):

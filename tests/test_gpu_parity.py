@@ -180,6 +180,7 @@ def test_distance_matrix_bit_exact(gpu_lib, oracle):
     cm = bliss_amd.cosine_matrix(v[:200])
     ref = np.array([[oracle.cosine(a, b) for b in v[:200]] for a in v[:200]], dtype=np.float32)
     assert np.array_equal(cm, ref)
+    assert np.array_equal(cm, oracle.cosine_matrix(v[:200]))
     a, b = _lib.ForceVector(*v[0]), _lib.ForceVector(*v[1])
     assert gpu_lib.bl_distance(a, b) == oracle.distance(v[0], v[1]) == dm[0, 1]
     assert gpu_lib.bl_cosine_similarity(a, b) == oracle.cosine(v[0], v[1])
@@ -460,6 +461,39 @@ def test_batches_on_two_streams_do_not_race(gpu_lib, oracle):
     for i in range(6):
         check_song(ra[i], oracle.analyze(pcm_a[i], 2, 8), ("stream1", i))
         check_song(rb[i], oracle.analyze(pcm_b[i], 1, 9), ("stream2", i))
+
+
+def test_cosine_matrix_bit_exact_including_degenerate_vectors(gpu_lib, oracle):
+    """bl_cosine_similarity for all pairs (ref src/analyze.c:135-140) through the guarded quotient of bl_cos.h: 3 000
+    vectors of mixed scale — ordinary force vectors, tiny and huge norms, a zero vector (0 / 0), duplicates and
+    sign flips (quotients of exactly +-1), orthogonal pairs (zero dot products) — every one of the 9 million
+    outputs has the bits of the CPU restatement, NaNs included."""
+    rng = np.random.default_rng(11)
+    v = (rng.standard_normal((3000, 4)) * 10).astype(np.float32)
+    v[100:200] *= np.float32(1e-18)
+    v[200:300] *= np.float32(1e17)
+    v[300] = 0
+    v[301] = v[5]; v[302] = -v[5]; v[303] = v[5] * np.float32(3)
+    v[304] = [1, 0, 0, 0]; v[305] = [0, 1, 0, 0]; v[306] = [0, 0, -2, 0]
+    v[310:330, 1:] = 0           # collinear along x: quotients of exactly +-1 at many scales
+    cm = bliss_amd.cosine_matrix(v)
+    ref = oracle.cosine_matrix(v)
+    assert np.array_equal(cm.view(np.int32), ref.view(np.int32)), int(np.count_nonzero(cm.view(np.int32) != ref.view(np.int32)))
+    assert np.isnan(cm[300]).all() and cm[301, 5] == 1.0 and cm[302, 5] == -1.0 and cm[304, 305] == 0.0
+
+
+def test_guarded_cosine_quotient_sweep(gpu_lib):
+    """bl_cos.h is not taken on trust: 2^33 pseudo-random (dot, |a|^2, |b|^2) triples — each random dot with its
+    eight neighbouring floats — on the device against the plain expression: no accepted fast result differs, the
+    double quotients never differ by more than the 3.5 ulp the guard of 16 is built on, and the sweep does meet
+    the float rounding boundaries the guard exists for (where the unguarded form is wrong)."""
+    counts = (C.c_uint64 * 6)()
+    assert gpu_lib.bl_amd_selftest_cos(counts, 1 << 33) == 0
+    n, n_fast, bad, max_ulp, near, near_bad = (int(x) for x in counts)
+    assert n >= 1 << 33 and bad == 0, (n, bad)
+    assert n_fast > 0.999 * n * 0.5 and max_ulp <= 4, (n_fast, max_ulp)   # zero / tiny dots and norms take the plain form
+    assert near > 100, near
+    print("cosine sweep:", dict(triples=n, fast=n_fast, max_ulp=max_ulp, near_boundary=near, unguarded_wrong=near_bad))
 
 
 def test_sqrt_of_the_distance_kernels_is_correctly_rounded(gpu_lib):
