@@ -464,6 +464,32 @@ def main():
     per_rank = per_rank.cpu().numpy()
 
     res = corpus.fetch()
+    # Untimed: the same batch once more in FIR mode 0 (the reference's operation order, window energies bit-identical
+    # to the CPU oracle) — what the timed default (mode 2: fused taps, normalisation folded in)
+    # buys, and whether any integer or feature of this batch depends on it.
+    fir_active = int(lib.bl_amd_fir_mode())
+    fir_report = {"timed_mode": fir_active}
+    if fir_active != 0:
+        lib.bl_amd_set_fir_mode(0)
+        lib.bl_amd_profile_reset()
+        lib.bl_amd_profile(1)
+        corpus.analyze()
+        torch.cuda.synchronize(dev)
+        lib.bl_amd_profile(0)
+        n0 = C.c_int(0)
+        ms0 = lib.bl_amd_profile_ms(b"env_windows", C.byref(n0))
+        res0 = corpus.fetch()
+        lib.bl_amd_set_fir_mode(fir_active)
+        ints = ("start", "end", "mean", "variance", "n_frames", "nb_frames", "n_windows", "beat", "calm_or_loud", "status")
+        flts = ("tempo", "amplitude", "frequency", "attack", "force")
+        fir_report.update({
+            "mode0_env_windows_ms": ms0 / max(n0.value, 1),
+            "timed_mode_env_windows_ms": kern["env_windows"]["ms_avg"],
+            "songs_with_an_integer_differing_from_mode0": int(sum(np.count_nonzero(res[k] != res0[k]) for k in ints)),
+            "songs_with_a_feature_bit_differing_from_mode0": int(sum(np.count_nonzero(res[k].view(np.int32) != res0[k].view(np.int32))
+                                                                   for k in flts)),
+            "what": "mode 0 = the reference's unfused FIR, one untimed pass over the same resident batch after the "
+                    "timed region; bl_amd_set_fir_mode(0) selects it"})
     ok = bool(np.all(res["status"] == 0) and np.all(np.isfinite(res["force"])))
     # the gathered vectors are the analysed ones, rank-major, and this rank's rows are distances
     ok = ok and bool(torch.equal(all_vecs[my_first:my_first + songs].cpu(),
@@ -586,7 +612,9 @@ def main():
                                    f"stereo songs resident per GPU ({songs * song_bytes / 1e9:.1f} GB PCM/GPU"
                                    + (", capped by free HBM" if capped else "")
                                    + f"), {total_songs} songs total, sharded by song; step = analyze + "
-                                     "all-gather of force vectors + row-block distance matrix",
+                                     "all-gather of force vectors + row-block distance matrix; envelope FIR mode "
+                                   + f"{fir_active} (library default; mode 0 = the reference's operation order, timed beside "
+                                     "it in fir_modes)",
                        "songs_per_gpu": songs, "song_samples": song_samples, "parallelism": f"shard{world}",
                        "generator": "integer-only device synth, seeds = global song index"},
             "distance_matrix_10k_s": dm_s,
@@ -596,7 +624,7 @@ def main():
             "cosine_matrix_10k_frac_hbm": dm_bytes / cm_s / 1e9 / HBM_PEAK_GBS,
             "whole_path_algorithmic_gbs_per_gpu": whole_path_gbs,
             "whole_path_frac_hbm": whole_path_gbs / HBM_PEAK_GBS,
-            "kernels_ms": kern, "results_ok": ok, "verified_songs": verified,
+            "kernels_ms": kern, "fir_modes": fir_report, "results_ok": ok, "verified_songs": verified,
             "verification": {"against": "CPU oracle (oracle/orc_cli) on the re-synthesised songs, untimed; every rank "
                                         "checks its share of --verify (results_ok / verified_songs are reduced over the "
                                         "ranks, the list below is rank 0's)",

@@ -812,8 +812,13 @@ __device__ __forceinline__ void ev_wave_sync() {
 #define EV_PROBE_ROUNDS 16
 #define EV_PROBE_SLOTS 12
 #ifndef BL_ENV_VARIANT
-#define BL_ENV_VARIANT 8 /* the variant the product launches */
+#define BL_ENV_VARIANT ((0x222111 << 8) | 8) /* the variant the product launches: bit 3, second half of a round at priority 2 */
 #endif
+/* the priority tables the measurement build instantiates (tools/env_ab.py --prio-tabs), hex, phase 0 in the lowest digit */
+#define EV_PRIO_TABS(X) X(0x222111) X(0x322211) X(0x322110) X(0x321000) X(0x000000) X(0x222110) X(0x222100)  \
+  X(0x221100) X(0x332110) X(0x333111) X(0x322111) X(0x222011) X(0x222112) X(0x222121) X(0x232111) X(0x322221)  \
+  X(0x333222) X(0x222000) X(0x111000) X(0x223111) X(0x233111) X(0x222211) X(0x332211) X(0x221000) X(0x211000)  \
+  X(0x322100)
 template <int FIR_MODE, int VAR>
 __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
@@ -991,6 +996,13 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
         else if (theirs > P) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(1);
       }
+    } else if (VAR >> 8) { /* bits 8..31: the priority of every phase, 4 bits per phase, a compile-time table */
+      constexpr int TAB = VAR >> 8;
+      const int pr = (TAB >> (4 * k)) & 3; /* k is a literal at every call: one s_setprio, no branch */
+      if (pr == 0) __builtin_amdgcn_s_setprio(0);
+      else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+      else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(3);
     } else if (VAR & 2) {
       if (exchange) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(1);
@@ -1193,6 +1205,21 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16 —
      * a mirror of the 16-lane row followed by a rotation by one, two DPP moves per dword and no LDS
      * round trip; lane 0 is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
+    double *tg = terms + (4 * wave + g) * EV_TROW;
+    if (VAR & 8) {
+      /* The rows are free once the summing wave has taken tile seq - 1 out of them.  Bit 3 waits for that in
+       * front of the power terms, not behind them: the second halves kept from the round before leave their
+       * registers first, this round's take their place as they are computed (no copies, 16 registers fewer
+       * live), and the stores of the first halves go out between the arithmetic instead of in one burst. */
+      stamp(s, 5);
+      phase(5, true);
+      while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
+      ev_lds_acquire();
+      stamp(s, 6);
+#pragma unroll
+      for (int k0 = 0; k0 < 8; ++k0)
+        if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0]; /* terms 130..256 of the round before */
+    }
     double own[8], mir[8];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
@@ -1205,27 +1232,23 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
       const double pi = bl_dpp_f64_old<0x111>(zi, bl_dpp_f64<0x140>(si));
       bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
                                       own[k0], mir[k0]);
+      if (VAR & 8) {
+        tg[l + 16 * k0] = own[k0]; /* terms 0..127 of this round */
+        held[k0] = mir[k0];
+      }
     }
     const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
     const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
-    stamp(s, 5);
-    phase(5, true);
-    double *tg = terms + (4 * wave + g) * EV_TROW;
-    /* the rows are free once the summing wave has taken tile seq - 1 out of them */
-    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
-    ev_lds_acquire();
-    stamp(s, 6);
     if (VAR & 8) {
-      /* terms 0..129 of this round (term 129 is lane 15's mir[7]) and terms 130..256 of the round before */
-#pragma unroll
-      for (int k0 = 0; k0 < 8; ++k0) {
-        tg[l + 16 * k0] = own[k0];
-        if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0];
-        held[k0] = mir[k0];
-      }
       if (l == 0) tg[128] = mid;
-      if (l == 15) tg[129] = mir[7];
+      if (l == 15) tg[129] = mir[7]; /* term 129 belongs to the first half */
     } else {
+      stamp(s, 5);
+      phase(5, true);
+      /* the rows are free once the summing wave has taken tile seq - 1 out of them */
+      while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
+      ev_lds_acquire();
+      stamp(s, 6);
 #pragma unroll
       for (int k0 = 0; k0 < 8; ++k0) {
         tg[l + 16 * k0] = own[k0];
@@ -1717,6 +1740,10 @@ int blk_configure_device(void) {
                          reinterpret_cast<const void *>(k_env_windows3<2, 10>),
                          reinterpret_cast<const void *>(k_env_windows3<2, 12>), reinterpret_cast<const void *>(k_env_windows3<2, 13>)})
     BL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+#define X(T) BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, ((T) << 8) | 8>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+  EV_PRIO_TABS(X)
+#undef X
 #endif
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
@@ -1742,6 +1769,7 @@ struct Mark {
 
 static long long *g_env_probe = nullptr;
 #ifdef BL_AMD_MEASURE
+
 /* measurement builds only: pick a scheduling variant at run time (-1: the compiled default) and give the probe
  * instantiations (bit 2) a device buffer of 8 x EV_PROBE_ROUNDS x EV_PROBE_SLOTS int64 for their s_memtime stamps */
 static int g_env_variant = -1;
@@ -1851,6 +1879,9 @@ int blk_analyze(const blk_analyze_args &a) {
         else if (var == 8) EV_LAUNCH(2, 8);
         else if (var == 9) EV_LAUNCH(2, 9);
         else if (var == 10) EV_LAUNCH(2, 10);
+#define X(T) else if (var == (((T) << 8) | 8)) EV_LAUNCH(2, ((T) << 8) | 8);
+        EV_PRIO_TABS(X)
+#undef X
         else if (var == 12) EV_LAUNCH(2, 12);
         else EV_LAUNCH(2, 13);
       } else

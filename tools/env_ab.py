@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--probe", default="4")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dump", default="", help="directory for the raw stamps (probe<v>.npy)")
+    ap.add_argument("--prio-tabs", default="", help="comma-separated hex tables for variant 24 (4 bits per phase, phase 0 lowest)")
     a = ap.parse_args()
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "bliss_amd", "csrc"), "measure"], check=True)
     os.environ["BLISS_AMD_LIB"] = os.path.join(ROOT, "bliss_amd", "libbliss_amd_measure.so")
@@ -69,6 +70,9 @@ def main():
         got, ms = run(v)
         out["variants"][str(v)] = {"env_windows_ms": ms, "vs_variant0": ms / base_ms,
                                    "records_identical": not diff(got), "fields_differing": diff(got)}
+    for tab in [t for t in a.prio_tabs.split(",") if t]:   # compile-time tables: bits 8.. of the variant, with bit 3
+        got, ms = run((int(tab, 16) << 8) | 8)
+        out["variants"][f"tab:{tab}"] = {"env_windows_ms": ms, "vs_variant0": ms / base_ms, "records_identical": not diff(got)}
     again, _ = run(0)
     out["variants"]["0"]["repeat_identical"] = not diff(again)
     for v in [int(x) for x in a.probe.split(",") if x]:
