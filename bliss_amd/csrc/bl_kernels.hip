@@ -717,15 +717,36 @@ __device__ __forceinline__ double bl_norm(int k, double rcp, double rcp_lo) {
 /* ------------------------------------------------------------------------- */
 /* k_env_windows3: normalise + FIR + DFT + ordered sum, wave-autonomous        */
 /*
- * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, so the ~230 VGPRs
- * the unrolled FIR / DFT code wants fit without spilling), no workgroup barrier inside the loop.
- * A compute wave owns 4 consecutive windows per round (one per 16-lane group) and does everything
- * for them out of its private LDS slice: 17-tap FIR, the four 512-point f64 DFTs with split re/im
- * exchanges, and the 4 x 257 power terms.  The f32-rounded, strictly ordered sum of
- * ref tempo_atk_sort.c:142-149 is a 771-deep dependent chain per window: it runs on the eighth
- * wave, one lane per window for the 28 windows of the tile, concurrently with the next round of
- * the compute waves (terms buffer handed over through two LDS sequence words; waves of one
- * workgroup are always co-resident, so the spin waits cannot deadlock).
+ * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, ~230 VGPRs), no workgroup
+ * barrier inside the loop.
+ *
+ * A compute wave walks a CONTIGUOUS run of rounds of four windows (one window per 16-lane group; the song's
+ * rounds are split evenly over the compute waves of its workgroups).  Its private LDS slice holds five blocks
+ * of 256 filtered samples as a ring: a round filters the 1 024 new samples (16 outputs per lane, from the 32
+ * samples the lane loads itself: no cross-lane shift) into the four places the previous round has released and
+ * finds the block it shares with that round where it was left.  Then the four 512-point f64 DFTs: inputs as
+ * aligned ds_read_b128, two radix-16 passes over 16 lanes x 16 registers with the re and im transposes through
+ * the place of the window's own block, partner values of the real-input split through DPP (row mirror + shift),
+ * and the 4 x 257 power terms.  The first round of a run is preceded by a short pass that filters the one block
+ * it cannot inherit.
+ *
+ * The f32-rounded, strictly ordered sum of ref tempo_atk_sort.c:142-149 is a dependent chain of three
+ * instructions per term.  It runs on the eighth wave, IN TWO HALVES ON TWICE THE LANES: a compute wave hands over
+ * terms 0..129 of the round it has just finished together with terms 130..256 of the round BEFORE (kept in 16
+ * registers for one round); the summing wave adds the first halves on lanes 0-27 and, continuing from the partial
+ * sums of its previous step, the second halves on lanes 32-59 — 390 dependent instructions per tile of 28 windows
+ * instead of 771, the same additions in the same order.  The energies leave one step later.  Hand-over through
+ * LDS sequence words (waves of one workgroup are always co-resident, so the bounded spins cannot deadlock).
+ *
+ * Who gets the VALU.  A SIMD gives its VALU to the wave with the highest s_setprio value and, among equals, to
+ * the OLDEST wave — strictly: 96 % of the issue slots to the older of two busy waves (tools/gen_ubench_issue.py).
+ * Two compute waves that share a SIMD and are held in step by the tile hand-over therefore do not share it: the
+ * older one runs its round and waits, the younger one then runs alone with every LDS round trip of its own
+ * exposed, and the tile waits for it.  PRIO gives every phase of a round a priority (4 bits per phase, phase 0 in
+ * the lowest digit); the shipped table 0x222111 runs the second half of a round (transposes, second DFT pass,
+ * hand-over, power terms) at 2 and the first at 1: whichever wave is further along — the one the tile is waiting
+ * for — wins, whatever its age.  278 vs 306 ms per 8 192 S180 songs with identical results
+ * (profiles/r04_env_variants.json).
  */
 #define EV_CWAVES 7
 #define EV_TILE (4 * EV_CWAVES)             /* windows per tile */
@@ -766,25 +787,6 @@ __device__ __forceinline__ void ev_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* ------------------------------------------------------------------------- */
-/* k_env_windows3: the same arithmetic, every FIR output computed once          */
-/*
- * k_env_windows2 filters 1 280 samples per round of four windows and keeps 1 024: the next
- * round of the wave is 28 windows away, so the 256 samples its first window shares with the
- * last one are filtered again (a quarter of the FIR, which is 43 % of the round).  Here a
- * compute wave walks a CONTIGUOUS run of windows (the song's rounds are split evenly over the
- * workgroups' compute waves).  The wave's slice holds five blocks of 256 filtered samples as a
- * ring: a round filters the 1 024 new samples (16 outputs per lane) into the four positions the
- * previous round has released and finds the block it shares with the previous round where that
- * round left it — nothing is copied.  The transposes of window g use the place of block g, which
- * every window has finished reading by then; the carried block is nobody's block g.  The partner
- * values of the real-input split come through DPP (row mirror + rotation), not through LDS: an LDS
- * round trip on the wave's critical path costs more than the moves.  Each lane normalises the 32 samples its 16 outputs read from its own loads: no
- * cross-lane shift, hence no lane 0 that would need the previous round's lane 63.  The first
- * round of a run is preceded by a short pass that filters the one block it cannot inherit.
- * Rounds, hand-over to the summing wave, DFT and power terms are those of k_env_windows2;
- * the energies are bit-identical.
- */
 #define EV3_BLK 288                          /* doubles per block: 16 rows of 16 samples + 2 pads */
 #define EV3_HEADS (5 * EV3_BLK)
 #define EV3_SLOTS (EV3_HEADS + 64)           /* + 4 x 16 window heads */
@@ -794,32 +796,15 @@ __device__ __forceinline__ void ev_wave_sync() {
 #define EV3_ZERO_OFF (EV3_FLAG_OFF + 128)   /* 16 bytes of zeros: the 65th term pair of a second-half lane */
 #define EV3_LDS_BYTES (EV3_ZERO_OFF + 16)
 
-/* VAR: scheduling variants, arithmetic untouched.  The VALU of a SIMD goes to the wave with
- * the highest s_setprio value and, among equals, to the OLDEST wave, strictly (tools/gen_ubench_issue.py: 96 % of
- * the issue slots to the older of two busy waves): two compute waves that share a SIMD and are held in step by
- * the tile hand-over do not share it — the older one runs its round, waits, and the younger one then runs alone
- * with every LDS round trip of its own exposed.
- *   bit 0  fair share: a wave publishes its progress at the phase boundaries and takes priority 2 while it is
- *          behind the wave it shares its SIMD with, 0 while it is ahead
- *   bit 1  the LDS exchange phases of a round (short bursts between round trips) run at priority 2, the long
- *          arithmetic phases at 1
- *   bit 2  measurement builds: s_memtime stamps of one workgroup's phases into `probe`
- *   bit 3  the ordered sum in two halves on twice the lanes: a compute wave hands over the terms 0..129 of the
- *          round it has just finished together with the terms 130..256 of the round BEFORE (kept in 16 registers for
- *          one round); the summing wave adds the first halves on lanes 0-27 and, continuing from the partial sums of
- *          its previous step, the second halves on lanes 32-59 — 390 dependent instructions per tile instead of 771
- *          for the same additions in the same order.  The energies leave one step later. */
 #define EV_PROBE_ROUNDS 16
 #define EV_PROBE_SLOTS 12
-#ifndef BL_ENV_VARIANT
-#define BL_ENV_VARIANT ((0x222111 << 8) | 8) /* the variant the product launches: bit 3, second half of a round at priority 2 */
+#ifndef BL_ENV_PRIO
+#define BL_ENV_PRIO 0x222111 /* the priority table the product launches */
 #endif
-/* the priority tables the measurement build instantiates (tools/env_ab.py --prio-tabs), hex, phase 0 in the lowest digit */
-#define EV_PRIO_TABS(X) X(0x222111) X(0x322211) X(0x322110) X(0x321000) X(0x000000) X(0x222110) X(0x222100)  \
-  X(0x221100) X(0x332110) X(0x333111) X(0x322111) X(0x222011) X(0x222112) X(0x222121) X(0x232111) X(0x322221)  \
-  X(0x333222) X(0x222000) X(0x111000) X(0x223111) X(0x233111) X(0x222211) X(0x332211) X(0x221000) X(0x211000)  \
-  X(0x322100)
-template <int FIR_MODE, int VAR>
+/* the priority tables the measurement build instantiates beside it (tools/env_ab.py) */
+#define EV_PRIO_TABS(X) X(0x000000) X(0x111111) X(0x322110) X(0x321000) X(0x222110) X(0x222011) X(0x232111) X(0x222112)
+/* PROBE (measurement builds): s_memtime stamps of one workgroup's phases into `probe` */
+template <int FIR_MODE, int PRIO, bool PROBE>
 __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
     const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc, long long *probe) {
@@ -829,12 +814,11 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
   c2d *tw512 = tw256 + 256;
   typedef __attribute__((address_space(3))) volatile int lds_vint;
   lds_vint *flags = (lds_vint *)(smem + EV3_FLAG_OFF); /* [0..6] published by the compute waves, [8] by the summing wave */
-  lds_vint *prog = flags + 16;                          /* VAR bit 0: progress words of the compute waves */
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, g = ln >> 4, l = ln & 15;
-  const bool probing = (VAR & 4) && blockIdx.x == 0 && blockIdx.y == 0 && probe != nullptr;
+  const bool probing = PROBE && blockIdx.x == 0 && blockIdx.y == 0 && probe != nullptr;
   auto stamp = [&](int round, int slot) {
-    if (VAR & 4) {
+    if (PROBE) {
       __builtin_amdgcn_sched_barrier(0); /* no arithmetic moves across a stamp */
       if (probing && round < EV_PROBE_ROUNDS && ln == 0)
         probe[(wave * EV_PROBE_ROUNDS + round) * EV_PROBE_SLOTS + slot] = (long long)__builtin_amdgcn_s_memtime();
@@ -848,8 +832,8 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     tw256[tid] = tb.tw256_d[((tid & 15) * (tid >> 4)) & 255];
     tw512[tid] = tb.tw512_d[tid];
   }
-  if (tid < 36) flags[tid] = 0; /* the two sets of sequence words and the zero pair behind them */
-  if ((VAR & 8) && tid < EV_TILE) terms[tid * EV_TROW + 257] = 0.0; /* the pad behind term 256: read as a term by bit 3 */
+  if (tid < 36) flags[tid] = 0; /* the sequence words and the zero pair behind them */
+  if (tid < EV_TILE) terms[tid * EV_TROW + 257] = 0.0; /* the pad behind term 256 is read as a term */
   __syncthreads();
 
   /* rounds of four windows, split evenly over the compute waves of the song's workgroups */
@@ -863,11 +847,9 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
   int seq = 0;
 
   if (wave == EV_CWAVES) {
-    /* ---- summing wave: lane 4 c + q sums window q of compute wave c's current round ---- */
+    /* ---- summing wave ---- */
     __builtin_amdgcn_s_setprio(3);
-    const int c = min(ln >> 2, EV_CWAVES - 1);
-    const int r0 = run_begin(u0 + c), r1 = run_begin(u0 + c + 1);
-    if (VAR & 8) {
+    {
       /* Step st (1-based): every compute wave has published st.  Lane i < 28 (row i) adds terms 0..129 of round st
        * starting from 0 and keeps the partial sum; lane 32 + i takes the partial sum lane i made in step st - 1 and
        * continues round st - 1 over terms 130..256, then stores the energy.  The second-half lanes read 127 terms and
@@ -937,76 +919,19 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
         }
         stamp(st - 1, 2);
       }
-      return;
-    }
-    for (int s = 0; s < steps; ++s) {
-      ++seq;
-      stamp(s, 0);
-      for (;;) {
-        const int f = ln < EV_CWAVES ? flags[ln] : seq;
-        if (__all(f >= seq)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      ev_lds_acquire();
-      stamp(s, 1);
-      const int rho = r0 + s, w = 4 * rho + (ln & 3);
-      if (ln < EV_TILE && rho < r1 && w < sg.n_windows) {
-        const double *tg = terms + ln * EV_TROW;
-        float sum = 0.f;
-        double ta[32], tb2[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) ta[k] = tg[k];
-#pragma unroll 1
-        for (int blk = 0; blk < 8; blk += 2) {
-#pragma unroll
-          for (int k = 0; k < 32; ++k) tb2[k] = tg[32 * (blk + 1) + k];
-#pragma unroll
-          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + ta[k]);
-          if (blk + 2 < 8) {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) ta[k] = tg[32 * (blk + 2) + k];
-          }
-#pragma unroll
-          for (int k = 0; k < 32; ++k) sum = (float)((double)sum + tb2[k]);
-        }
-        sum = (float)((double)sum + tg[256]);
-        energies[sg.env_off + w] = sum;
-        lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
-      }
-      ev_lds_release();
-      if (ln == 0) flags[8] = seq;
-      stamp(s, 2);
     }
     return;
   }
 
   /* ---- compute waves ---- */
-  /* phase boundary k (0..5) of round seq: publish, compare with what the partner had published one boundary
-   * ago (the read issued then has long landed), choose the priority for the phase that starts here */
-  const int partner = wave < 3 ? wave + 4 : wave - 4; /* waves w and w + 4 share SIMD w; wave 3 shares with the summing wave */
-  int seen = 0;
-  auto phase = [&](int k, bool exchange) {
-    if (VAR & 1) {
-      const int P = 6 * seq + k;
-      if (wave != 3) {
-        const int theirs = __builtin_amdgcn_readfirstlane(seen);
-        prog[wave] = P;
-        seen = prog[partner];
-        if (theirs < P - 1) __builtin_amdgcn_s_setprio(0);
-        else if (theirs > P) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(1);
-      }
-    } else if (VAR >> 8) { /* bits 8..31: the priority of every phase, 4 bits per phase, a compile-time table */
-      constexpr int TAB = VAR >> 8;
-      const int pr = (TAB >> (4 * k)) & 3; /* k is a literal at every call: one s_setprio, no branch */
-      if (pr == 0) __builtin_amdgcn_s_setprio(0);
-      else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-      else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(3);
-    } else if (VAR & 2) {
-      if (exchange) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(1);
-    }
+  /* phase boundary k (0..5) of a round: the priority of the phase that starts here.  k is a literal at every
+   * call: one s_setprio (which is also a scheduling barrier: the phases stay apart in the instruction stream) */
+  auto phase = [&](int k) {
+    const int pr = (PRIO >> (4 * k)) & 3;
+    if (pr == 0) __builtin_amdgcn_s_setprio(0);
+    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
   };
   double *buf = reinterpret_cast<double *>(smem) + wave * EV3_SLOTS;
   const int mean = st.mean;
@@ -1067,10 +992,10 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     preh = p[min(1024 * rho_ + 256 * g + l, n_used - 1)];
   };
   fetch(r0);
-  double held[8]; /* VAR bit 3: mir[] of the previous round */
+  double held[8]; /* terms 130..256 (mir[]) of the previous round */
 #pragma unroll
   for (int k0 = 0; k0 < 8; ++k0) held[k0] = 0.0;
-  /* VAR bit 3: a publication that carries nothing but the second halves of the round before */
+  /* a publication that carries nothing but the second halves of the round before */
   auto publish_held_only = [&]() {
     while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
     ev_lds_acquire();
@@ -1084,13 +1009,12 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     ++seq;
     const int rho = r0 + s;
     if (rho >= r1) { /* this wave's run is one round shorter than its neighbours': nothing to hand over */
-      if (VAR & 8) publish_held_only();
+      publish_held_only();
       if (ln == 0) flags[wave] = seq;
-      if (VAR & 1) prog[wave] = 6 * seq + 12;
       continue;
     }
     stamp(s, 0);
-    phase(0, false);
+    phase(0);
     /* 1. normalise (ref :109-114) the 32 samples into registers */
     double yv[16], yh;
     {
@@ -1155,7 +1079,7 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     const int pa = xa >= 5 ? xa - 5 : xa, pb = xb >= 5 ? xb - 5 : xb;
     double *blk_a = buf + pa * EV3_BLK, *blk_b = buf + pb * EV3_BLK;
     stamp(s, 1);
-    phase(1, true);
+    phase(1);
     ev_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
 #pragma unroll
     for (int i = 0; i < 16; ++i) blk_b[18 * l + i] = yv[i];
@@ -1176,7 +1100,7 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     }
     ev_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
     stamp(s, 2);
-    phase(2, false);
+    phase(2);
     bl_fft16(re, im);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
@@ -1184,7 +1108,7 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
       bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w.re, w.im);
     }
     stamp(s, 3);
-    phase(3, true);
+    phase(3);
     double *xg = blk_a; /* [16][18] doubles, re then im */
     const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
 #pragma unroll
@@ -1200,27 +1124,28 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
     ev_wave_sync();
     stamp(s, 4);
-    phase(4, false);
+    phase(4);
     bl_fft16(re, im);
     /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16 —
      * a mirror of the 16-lane row followed by a rotation by one, two DPP moves per dword and no LDS
      * round trip; lane 0 is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
     double *tg = terms + (4 * wave + g) * EV_TROW;
-    if (VAR & 8) {
-      /* The rows are free once the summing wave has taken tile seq - 1 out of them.  Bit 3 waits for that in
-       * front of the power terms, not behind them: the second halves kept from the round before leave their
-       * registers first, this round's take their place as they are computed (no copies, 16 registers fewer
-       * live), and the stores of the first halves go out between the arithmetic instead of in one burst. */
-      stamp(s, 5);
-      phase(5, true);
-      while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
-      ev_lds_acquire();
-      stamp(s, 6);
+    /* The rows are free once the summing wave has taken tile seq - 1 out of them.  The wait stands in front of the
+     * power terms, not behind them: the second halves kept from the round before leave their registers first, this
+     * round's take their place as they are computed (no copies, 16 registers fewer live), and the stores of the
+     * first halves go out between the arithmetic instead of in one burst. */
+    stamp(s, 5);
+    phase(5);
+    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
+    ev_lds_acquire();
+    stamp(s, 6);
 #pragma unroll
-      for (int k0 = 0; k0 < 8; ++k0)
-        if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0]; /* terms 130..256 of the round before */
-    }
-    double own[8], mir[8];
+    for (int k0 = 0; k0 < 8; ++k0)
+      if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0]; /* terms 130..256 of the round before */
+    /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16 —
+     * a mirror of the 16-lane row followed by a shift by one, two DPP moves per dword and no LDS
+     * round trip; lane 0 is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
+    double mir7 = 0.0;
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
       const double sr = re[bl_pos16(15 - k0)], si = im[bl_pos16(15 - k0)];
@@ -1230,46 +1155,27 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
        * `old`, which is what it needs instead — its own register */
       const double pr = bl_dpp_f64_old<0x111>(zr, bl_dpp_f64<0x140>(sr));
       const double pi = bl_dpp_f64_old<0x111>(zi, bl_dpp_f64<0x140>(si));
-      bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0],
-                                      own[k0], mir[k0]);
-      if (VAR & 8) {
-        tg[l + 16 * k0] = own[k0]; /* terms 0..127 of this round */
-        held[k0] = mir[k0];
-      }
+      double own;
+      bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0], own, held[k0]);
+      tg[l + 16 * k0] = own; /* terms 0..127 of this round */
+      if (k0 == 7) mir7 = held[7];
     }
+    /* |X_128|^2 = |Z_128|^2 has no 1/4 of its own: give back the one the halved input took */
     const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
     const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
-    if (VAR & 8) {
-      if (l == 0) tg[128] = mid;
-      if (l == 15) tg[129] = mir[7]; /* term 129 belongs to the first half */
-    } else {
-      stamp(s, 5);
-      phase(5, true);
-      /* the rows are free once the summing wave has taken tile seq - 1 out of them */
-      while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
-      ev_lds_acquire();
-      stamp(s, 6);
-#pragma unroll
-      for (int k0 = 0; k0 < 8; ++k0) {
-        tg[l + 16 * k0] = own[k0];
-        tg[256 - l - 16 * k0] = mir[k0];
-      }
-      if (l == 0) tg[128] = mid;
-    }
+    if (l == 0) tg[128] = mid;
+    if (l == 15) tg[129] = mir7; /* term 129 belongs to the first half */
     /* The LDS executes one wave's instructions in order: the sequence word below lands after the terms above
-     * whether this wave waits for them or not, and nothing in the next round needs them.  Bit 3 does not wait
-     * (~1 k cycles of LDS queue per round, with no arithmetic to cover them). */
-    if (!(VAR & 8)) ev_lds_release();
+     * whether this wave waits for them or not, and nothing in the next round needs them: no wait (~1 k cycles
+     * of LDS queue per round with no arithmetic to cover them). */
     ev_wave_sync();
     if (ln == 0) flags[wave] = seq;
     stamp(s, 7);
     base5 = base5 == 0 ? 4 : base5 - 1; /* (4 (rho + 1)) mod 5 */
   }
-  if (VAR & 8) { /* the second halves of the last round: one more publication, nothing else in it */
-    ++seq;
-    publish_held_only();
-    if (ln == 0) flags[wave] = seq;
-  }
+  ++seq; /* the second halves of the last round: one more publication, nothing else in it */
+  publish_held_only();
+  if (ln == 0) flags[wave] = seq;
 }
 #undef FC
 
@@ -1728,20 +1634,18 @@ bl_tables blk_tables_bind(const void *d_mem) {
 }
 
 int blk_configure_device(void) {
-  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows3<0, BL_ENV_VARIANT>),
-                         reinterpret_cast<const void *>(k_env_windows3<1, BL_ENV_VARIANT>),
-                         reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_VARIANT>)})
+  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows3<0, BL_ENV_PRIO, false>),
+                         reinterpret_cast<const void *>(k_env_windows3<1, BL_ENV_PRIO, false>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_PRIO, false>)})
     BL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
 #ifdef BL_AMD_MEASURE
-  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows3<2, 0>), reinterpret_cast<const void *>(k_env_windows3<2, 1>),
-                         reinterpret_cast<const void *>(k_env_windows3<2, 2>), reinterpret_cast<const void *>(k_env_windows3<2, 4>),
-                         reinterpret_cast<const void *>(k_env_windows3<2, 5>), reinterpret_cast<const void *>(k_env_windows3<2, 6>),
-                         reinterpret_cast<const void *>(k_env_windows3<2, 8>), reinterpret_cast<const void *>(k_env_windows3<2, 9>),
-                         reinterpret_cast<const void *>(k_env_windows3<2, 10>),
-                         reinterpret_cast<const void *>(k_env_windows3<2, 12>), reinterpret_cast<const void *>(k_env_windows3<2, 13>)})
-    BL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
-#define X(T) BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, ((T) << 8) | 8>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_PRIO, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
+#define X(T)                                                                                              \
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, T, false>),           \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));           \
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, T, true>),            \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
   EV_PRIO_TABS(X)
 #undef X
 #endif
@@ -1770,8 +1674,8 @@ struct Mark {
 static long long *g_env_probe = nullptr;
 #ifdef BL_AMD_MEASURE
 
-/* measurement builds only: pick a scheduling variant at run time (-1: the compiled default) and give the probe
- * instantiations (bit 2) a device buffer of 8 x EV_PROBE_ROUNDS x EV_PROBE_SLOTS int64 for their s_memtime stamps */
+/* measurement builds only: pick a priority table of EV_PRIO_TABS at run time (-1: the compiled default; bits 24..:
+ * the PROBE instantiation) and give the stamps a device buffer of 8 x EV_PROBE_ROUNDS x EV_PROBE_SLOTS int64 */
 static int g_env_variant = -1;
 extern "C" __attribute__((visibility("default"))) int bl_amd_measure_env(int variant, void *d_probe) {
   g_env_variant = variant;
@@ -1860,35 +1764,29 @@ int blk_analyze(const blk_analyze_args &a) {
     /* one 512-thread workgroup per CU; the blocks of a song split its rounds of four windows
      * into contiguous runs, one per compute wave: at least four rounds per run, so that the
      * block a run filters before its first round stays a small part of it */
-    auto launch_env = [&](int first, int count, int maxn) {
+    auto launch_env = [&](int first, int count, int maxn) -> int {
       Mark m(a.mark, a.mark_user, PK_ENV, stream);
       const int gx2 = grid_x_for(std::max(1, (2 * (maxn / 512)) / (4 * 4 * EV_CWAVES)), count, 2, a.n_cu);
       const dim3 grid(gx2, count), block(64 * (EV_CWAVES + 1));
-#define EV_LAUNCH(M, V)                                                                              \
-  hipLaunchKernelGGL((k_env_windows3<M, V>), grid, block, EV3_LDS_BYTES, stream, a.pcm, a.songs + first, \
+#define EV_LAUNCH(M, T, P)                                                                           \
+  hipLaunchKernelGGL((k_env_windows3<M, T, P>), grid, block, EV3_LDS_BYTES, stream, a.pcm, a.songs + first, \
                      a.stats + first, a.tb, a.energies, a.lc, g_env_probe)
 #ifdef BL_AMD_MEASURE
-      const int var = g_env_variant;
-      if (fir_mode == 2 && var >= 0 && var != BL_ENV_VARIANT) { /* bl_amd_measure_env(): A/B of the scheduling variants */
-        if (var == 0) EV_LAUNCH(2, 0);
-        else if (var == 1) EV_LAUNCH(2, 1);
-        else if (var == 2) EV_LAUNCH(2, 2);
-        else if (var == 4) EV_LAUNCH(2, 4);
-        else if (var == 5) EV_LAUNCH(2, 5);
-        else if (var == 6) EV_LAUNCH(2, 6);
-        else if (var == 8) EV_LAUNCH(2, 8);
-        else if (var == 9) EV_LAUNCH(2, 9);
-        else if (var == 10) EV_LAUNCH(2, 10);
-#define X(T) else if (var == (((T) << 8) | 8)) EV_LAUNCH(2, ((T) << 8) | 8);
+      /* bl_amd_measure_env(): A/B of the priority tables (FIR mode 2 only), with or without the phase stamps */
+      const int tab = g_env_variant & 0xFFFFFF;
+      const bool stamps = g_env_variant >= 0 && (g_env_variant >> 24) != 0;
+      if (fir_mode == 2 && g_env_variant >= 0 && (tab != BL_ENV_PRIO || stamps)) {
+        if (tab == BL_ENV_PRIO) EV_LAUNCH(2, BL_ENV_PRIO, true);
+#define X(T) else if (tab == (T)) { if (stamps) EV_LAUNCH(2, T, true); else EV_LAUNCH(2, T, false); }
         EV_PRIO_TABS(X)
 #undef X
-        else if (var == 12) EV_LAUNCH(2, 12);
-        else EV_LAUNCH(2, 13);
+        else return BL_UNEXPECTED;
       } else
 #endif
-      if (fir_mode == 2) EV_LAUNCH(2, BL_ENV_VARIANT);
-      else if (fir_mode == 1) EV_LAUNCH(1, BL_ENV_VARIANT);
-      else EV_LAUNCH(0, BL_ENV_VARIANT);
+      if (fir_mode == 2) EV_LAUNCH(2, BL_ENV_PRIO, false);
+      else if (fir_mode == 1) EV_LAUNCH(1, BL_ENV_PRIO, false);
+      else EV_LAUNCH(0, BL_ENV_PRIO, false);
+      return BL_OK;
 #undef EV_LAUNCH
     };
     /* the serial tail of the songs [first, first + count), on the side stream when there is something to
@@ -1913,13 +1811,12 @@ int blk_analyze(const blk_analyze_args &a) {
      * under the window kernel of the rest. */
     const int n_head = (a.n_head > 0 && a.n_head < n_songs && side) ? a.n_head : 0;
     if (n_head) {
-      launch_env(0, n_head, a.max_n);
-      if (launch_tail(0, n_head) != BL_OK) return BL_UNEXPECTED;
-      launch_env(n_head, n_songs - n_head, a.max_n_rest);
-      if (launch_tail(n_head, n_songs - n_head) != BL_OK) return BL_UNEXPECTED;
+      if (launch_env(0, n_head, a.max_n) != BL_OK || launch_tail(0, n_head) != BL_OK) return BL_UNEXPECTED;
+      if (launch_env(n_head, n_songs - n_head, a.max_n_rest) != BL_OK ||
+          launch_tail(n_head, n_songs - n_head) != BL_OK)
+        return BL_UNEXPECTED;
     } else {
-      launch_env(0, n_songs, a.max_n);
-      if (launch_tail(0, n_songs) != BL_OK) return BL_UNEXPECTED;
+      if (launch_env(0, n_songs, a.max_n) != BL_OK || launch_tail(0, n_songs) != BL_OK) return BL_UNEXPECTED;
     }
     if (tail_async) BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
   }

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""A/B of the scheduling variants of k_env_windows3 (measurement build, bl_amd_measure_env): the same resident
-corpus analysed by every variant, results compared bit for bit with variant 0, the kernel timed with HIP events,
-and — for the probe instantiations (bit 2) — the s_memtime stamps of workgroup (0, 0) summarised per wave:
-where a compute wave's round goes (arithmetic phases, exchange phases, the wait in front of the hand-over).
-Prints one JSON object.
-usage: python tools/env_ab.py [--songs 1024] [--seconds 180] [--variants 0,1,2] [--probe 4,5] [--reps 3]"""
+"""A/B of the phase-priority tables of k_env_windows3 (measurement build, bl_amd_measure_env): the same resident
+corpus analysed with every table, results compared field by field with the shipped table's, the kernel timed with
+HIP events, and — for --probe tables — the s_memtime stamps of workgroup (0, 0) summarised per wave: where a
+compute wave's round goes (arithmetic phases, exchange phases, the wait in front of the hand-over).
+A table is six hex digits, one priority (0..3) per phase, phase 0 in the lowest digit; the measurement build
+instantiates the ones of EV_PRIO_TABS (bl_kernels.hip) beside the shipped 222111.  Prints one JSON object.
+usage: python tools/env_ab.py [--songs 1024] [--seconds 180] [--tabs 000000,111111,322110] [--probe 222111] [--reps 3]"""
 import argparse
 import ctypes as C
 import json
@@ -17,18 +18,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROBE_ROUNDS, PROBE_SLOTS = 16, 12
-SLOTS = ["start", "fir_done", "inputs_loaded", "fft1_done", "exchanged", "power_done", "handover_passed", "published"]
+SLOTS = ["start", "fir_done", "inputs_loaded", "fft1_done", "exchanged", "fft2_done", "rows_free", "published"]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--songs", type=int, default=1024)
     ap.add_argument("--seconds", type=int, default=180)
-    ap.add_argument("--variants", default="0,1,2")
-    ap.add_argument("--probe", default="4")
+    ap.add_argument("--tabs", default="000000,111111,322110,321000,222110,222011,232111,222112")
+    ap.add_argument("--probe", default="")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dump", default="", help="directory for the raw stamps (probe<v>.npy)")
-    ap.add_argument("--prio-tabs", default="", help="comma-separated hex tables for variant 24 (4 bits per phase, phase 0 lowest)")
     a = ap.parse_args()
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "bliss_amd", "csrc"), "measure"], check=True)
     os.environ["BLISS_AMD_LIB"] = os.path.join(ROOT, "bliss_amd", "libbliss_amd_measure.so")
@@ -42,11 +42,13 @@ def main():
     torch.cuda.synchronize()
     probe = torch.zeros(8 * PROBE_ROUNDS * PROBE_SLOTS, dtype=torch.int64, device="cuda")
 
-    def run(var, with_probe=False):
+    def run(tab, with_probe=False):
         probe.zero_()
-        lib.bl_amd_measure_env(var, C.c_void_p(probe.data_ptr()) if with_probe else None)
+        var = -1 if tab is None else (int(tab, 16) | ((1 << 24) if with_probe else 0))
+        assert lib.bl_amd_measure_env(var, C.c_void_p(probe.data_ptr()) if with_probe else None) == 0
         corpus.analyze()
         got = corpus.fetch()
+        assert int(got["status"].max()) == 0, f"table {tab} is not instantiated (EV_PRIO_TABS)"
         lib.bl_amd_profile_reset()
         lib.bl_amd_profile(1)
         for _ in range(a.reps):
@@ -57,30 +59,24 @@ def main():
         ms = lib.bl_amd_profile_ms(b"env_windows", C.byref(k))
         return got, ms / max(k.value, 1)
 
-    base, base_ms = run(0)
+    base, base_ms = run(None)
 
     def diff(got):  # field by field, bit patterns (the records carry 4 bytes of padding that nothing writes)
         bits = lambda x: x.view(np.int32) if x.dtype == np.float32 else x.view(np.int64) if x.dtype == np.float64 else x
         return {k: int(np.count_nonzero(bits(got[k]) != bits(base[k]))) for k in got.dtype.names
                 if np.count_nonzero(bits(got[k]) != bits(base[k]))}
-    out = {"songs": a.songs, "seconds": a.seconds, "variants": {"0": {"env_windows_ms": base_ms}}}
-    for v in [int(x) for x in a.variants.split(",") if x]:
-        if v == 0:
-            continue
-        got, ms = run(v)
-        out["variants"][str(v)] = {"env_windows_ms": ms, "vs_variant0": ms / base_ms,
-                                   "records_identical": not diff(got), "fields_differing": diff(got)}
-    for tab in [t for t in a.prio_tabs.split(",") if t]:   # compile-time tables: bits 8.. of the variant, with bit 3
-        got, ms = run((int(tab, 16) << 8) | 8)
-        out["variants"][f"tab:{tab}"] = {"env_windows_ms": ms, "vs_variant0": ms / base_ms, "records_identical": not diff(got)}
-    again, _ = run(0)
-    out["variants"]["0"]["repeat_identical"] = not diff(again)
-    for v in [int(x) for x in a.probe.split(",") if x]:
-        got, ms = run(v, True)
+    out = {"songs": a.songs, "seconds": a.seconds, "tables": {"shipped": {"env_windows_ms": base_ms}}}
+    for tab in [t for t in a.tabs.split(",") if t]:
+        got, ms = run(tab)
+        out["tables"][tab] = {"env_windows_ms": ms, "vs_shipped": ms / base_ms, "records_identical": not diff(got)}
+    again, _ = run(None)
+    out["tables"]["shipped"]["repeat_identical"] = not diff(again)
+    for tab in [t for t in a.probe.split(",") if t]:
+        got, ms = run(tab, True)
         st = probe.cpu().numpy().reshape(8, PROBE_ROUNDS, PROBE_SLOTS)
         if a.dump:
-            np.save(os.path.join(a.dump, f"probe{v}.npy"), st)
-        rep = {"env_windows_ms": ms, "records_identical": not diff(got), "fields_differing": diff(got), "waves": {}}
+            np.save(os.path.join(a.dump, f"probe_{tab}.npy"), st)
+        rep = {"env_windows_ms": ms, "records_identical": not diff(got), "waves": {}}
         for w in range(7):
             t = st[w, 4:PROBE_ROUNDS, :8].astype(np.float64)  # steady-state rounds
             if not t[:, 0].all():
@@ -95,7 +91,8 @@ def main():
             rep["summing_wave"] = {"wait_for_tile": round(float((t[:, 1] - t[:, 0]).mean())),
                                    "pass": round(float((t[:, 2] - t[:, 1]).mean())),
                                    "period": round(float(np.diff(t[:, 0]).mean()))}
-        out["variants"][f"probe{v}"] = rep
+        out["tables"][f"probe:{tab}"] = rep
+    lib.bl_amd_measure_env(-1, None)
     print(json.dumps(out, indent=1))
 
 
