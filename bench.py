@@ -313,6 +313,8 @@ def main():
                     help="0 = configs[2] shard (8192) if it fits in HBM, else the largest count that does")
     ap.add_argument("--seconds", type=int, default=SONG_SECONDS, help="song length (default 180)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mode0-pass", action="store_true",
+                    help="skip the untimed extra pass in FIR mode 0 (profiling runs: one envelope launch per step)")
     ap.add_argument("--cpu-ladder", default="1,8,32,64,128,256",
                     help="concurrent oracle processes per rung of the CPU baseline (tests shorten it)")
     ap.add_argument("--verify", type=int, default=32,
@@ -469,7 +471,7 @@ def main():
     # buys, and whether any integer or feature of this batch depends on it.
     fir_active = int(lib.bl_amd_fir_mode())
     fir_report = {"timed_mode": fir_active}
-    if fir_active != 0:
+    if fir_active != 0 and not args.no_mode0_pass:
         lib.bl_amd_set_fir_mode(0)
         lib.bl_amd_profile_reset()
         lib.bl_amd_profile(1)

@@ -25,6 +25,28 @@ def test_committed_profile_is_read_and_scaled():
     assert 2.9 < p["whole_step_traffic_ratio"] < 3.3
 
 
+def test_committed_profile_belongs_to_the_committed_kernels():
+    """The bench line scales the counters of the newest profiles/*_hbm_traffic.json to its launch: that profile must
+    have been taken at (or after) the last commit that touched the kernels, or its numbers describe other code."""
+    import subprocess
+    import pytest
+    p = bench._committed_profile(8192, bench.SONG_SAMPLES)
+    head = (p.get("git_head") or "").split("+")[0]
+    git = ["git", "-C", ROOT]
+    try:
+        last = subprocess.run(git + ["log", "-1", "--format=%H", "--", "bliss_amd/csrc/bl_kernels.hip", "bliss_amd/csrc/bl_fft.h"],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True).stdout.strip()
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("not a git checkout")
+    if not last:
+        pytest.skip("no history for the kernels")
+    assert head, f"{p['file']} carries no git_head"
+    assert "uncommitted" not in (p.get("git_head") or ""), f"{p['file']} was taken on uncommitted kernel sources"
+    r = subprocess.run(git + ["merge-base", "--is-ancestor", last, head], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, (f"{p['file']} was taken at {head[:12]}, the kernels last changed in {last[:12]}: "
+                               "regenerate it (tools/make_profiles.sh)")
+
+
 def test_missing_profile_is_an_explicit_error(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     p = bench._committed_profile(8192, bench.SONG_SAMPLES)
