@@ -107,6 +107,42 @@ print(json.dumps({"enqueue": t1 - t0, "total": t2 - t0}))
     assert t["enqueue"] < 0.5 * t["total"], t     # ~14 ms of kernels behind a sub-millisecond enqueue
 
 
+def test_mixed_batch_with_early_tail_equals_the_plain_path(oracle, tmp_path):
+    """A mixed-length group of >= 1 024 songs gives its longest songs their own window launch and starts their serial
+    tail under the window kernel of the rest (blk_analyze, n_head).  Same records as the same corpus analysed in
+    launch groups too small to be split (fresh process, BL_AMD_GROUP_SONGS=500), and a sample of them against the
+    oracle."""
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch, bliss_amd
+rng = np.random.default_rng(77)
+lengths = np.floor(np.exp(rng.uniform(np.log(6000), np.log(260000), 1400))).astype(np.int64)
+chans = rng.integers(1, 3, 1400)
+lengths = (lengths // chans) * chans
+c = bliss_amd.DeviceCorpus(lengths.tolist(), chans.tolist(), [3] * 1400)
+c.synth(seed_base=31000, sample_rate=22050)
+c.analyze(); r = c.fetch()
+assert int(r["status"].max()) == 0
+np.save(sys.argv[1], r)
+np.save(sys.argv[1] + ".len.npy", np.stack([lengths, chans]))
+''' % ROOT
+    outs = {}
+    for tag, env in (("split", {}), ("groups", {"BL_AMD_GROUP_SONGS": "500"})):
+        f = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), text=True,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(f)
+    _same(outs["split"], outs["groups"])
+    lengths, chans = np.load(str(tmp_path / "split.npy.len.npy"))
+    order = np.argsort(-lengths)
+    for i in [int(order[0]), int(order[255]), int(order[256]), int(order[700]), int(order[-1])]:
+        ref = oracle.analyze(oracle.synth(31000 + i, 22050, int(chans[i]), int(lengths[i])), int(chans[i]), 3)
+        check_song(outs["split"][i], ref, f"song {i} of the split batch ({lengths[i]} samples)")
+
+
 def test_measurement_switches_are_ignored_by_the_product_build(tmp_path):
     """The result-invalidating measurement aids (BL_AMD_SQRT_VARIANT=3: the distance kernel's store stream alone,
     BL_AMD_ENV_DBG: ordered sums skipped, BL_AMD_ENV_OLD, BL_AMD_NO_SIDE) only exist in `make measure` builds
