@@ -1,3 +1,7 @@
+// SUPERSEDED by tools/gen_ubench_issue.py (round 4): the percentages this tool prints include two things that are
+// not issue limits — a taken branch per 32-64 instructions (~150 cycles each) and the tail in which the waves that
+// were served first (the oldest wave of a SIMD gets 96 % of the slots) have finished and the others run alone.
+// Measured for a fixed time instead of a fixed amount of work, two waves per SIMD issue f64 at 99.5 % of the rate.
 // How much of the f64 VALU issue rate can W waves per SIMD reach?  One workgroup per CU (a 100 KB
 // LDS allocation keeps a second one out), 64 * 4 * W threads, every wave runs N iterations of C
 // independent v_fma_f64 chains (+ optionally LDS round trips between the bursts, like a kernel that
