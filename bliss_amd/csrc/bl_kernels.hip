@@ -927,11 +927,7 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
   /* phase boundary k (0..5) of a round: the priority of the phase that starts here.  k is a literal at every
    * call: one s_setprio (which is also a scheduling barrier: the phases stay apart in the instruction stream) */
   auto phase = [&](int k) {
-    int pr = (PRIO >> (4 * k)) & 3;
-#ifdef EV_YOUNG_BOOST
-    if (wave >= 4) pr = min(pr + EV_YOUNG_BOOST, 3);
-    if (pr < 0) pr = 0;
-#endif
+    const int pr = (PRIO >> (4 * k)) & 3;
     if (pr == 0) __builtin_amdgcn_s_setprio(0);
     else if (pr == 1) __builtin_amdgcn_s_setprio(1);
     else if (pr == 2) __builtin_amdgcn_s_setprio(2);
