@@ -194,7 +194,7 @@ def _committed_profile(songs, song_samples):
     try:
         tj = json.load(open(files[-1]))
         kernels = tj["kernels"]
-        tk = kernels.get("k_env_windows3") or kernels["k_env_windows2"]
+        tk = kernels["k_env_windows3"]
         scale = song_samples / 15876000.0
         out["traffic"] = tk["hbm_bytes_per_song"] * songs * scale
         out["git_head"] = tj.get("git_head")

@@ -145,7 +145,7 @@ np.save(sys.argv[1] + ".len.npy", np.stack([lengths, chans]))
 
 def test_measurement_switches_are_ignored_by_the_product_build(tmp_path):
     """The result-invalidating measurement aids (BL_AMD_SQRT_VARIANT=3: the distance kernel's store stream alone,
-    BL_AMD_ENV_DBG: ordered sums skipped, BL_AMD_ENV_OLD, BL_AMD_NO_SIDE) only exist in `make measure` builds
+    BL_AMD_NO_SIDE, and the round-3 switches BL_AMD_ENV_DBG / BL_AMD_ENV_OLD, whose code is gone) only exist in `make measure` builds
     (-DBL_AMD_MEASURE); the shipped library must give the same records, window energies and distance matrix
     whether those variables are set or not."""
     code = r'''

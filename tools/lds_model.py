@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LDS bank-conflict model for the access patterns of k_env_windows2 (k_env_windows3 keeps its exchange layouts) (MI355X_MICROARCH.md, LDS
+"""LDS bank-conflict model for the exchange layouts of k_env_windows3 (inherited from its round-2 predecessor) (MI355X_MICROARCH.md, LDS
 section): per instruction the wave is served in fixed lane groups, one LDS cycle per group when
 conflict-free; each extra distinct address on a busy bank adds one cycle.  Prints cycles per
 wave-instruction for every pattern (ideal in brackets)."""
