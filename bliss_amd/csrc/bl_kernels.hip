@@ -1039,7 +1039,9 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
         yv[i] = BL_FIR_SEL(FIR_MODE, XR, FC);
 #undef XR
       }
-      /* zero-state heads of the four windows, as in k_env_windows2.  Mode 2 gathers the taps as
+      /* zero-state heads of the four windows: the first 16 outputs of a window start from a zeroed delay line
+       * (ref :121); lane (g, l) filters sample l of window g with the taps that exist, tap m being the sample of
+       * lane l - m of the same 16-lane row, zero when there is none (DPP row_shr:m).  Mode 2 gathers the taps as
        * integers: the pair sums k[l - m] + k[l - 16 + m] are exact either way, a 32-bit DPP move
        * costs half of a 64-bit one and folds into the add, and only the nine sums are converted —
        * 34 instead of 49 instructions, the same bits */
