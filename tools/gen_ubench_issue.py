@@ -99,6 +99,19 @@ body("fir_serial", fir(1), note="8 outputs x 17 ops, one chain at a time (hipcc'
 body("fir_x2", fir(2), note="two outputs interleaved")
 body("fir_x4", fir(4), note="four outputs interleaved")
 body("cndmask_e64", [f"v_cndmask_b32_e64 v{64 + (i % 32)}, v{32 + (i % 32)}, v6, s[30:31]" for i in range(64)])
+# the f64 matrix pipe: v_mfma_f64_16x16x4_f64 (1024 fma per instruction) alone, back to back on one accumulator, and
+# with N independent v_fma_f64 behind each one — does the vector f64 pipe run beside it, from the same wave and from
+# the other wave of the SIMD?  A = v[2:3] (1.0), B = v[4:5] (0.0), accumulators v[64:71] .. v[88:95].
+ACC = [f"v[{64 + 8 * i}:{71 + 8 * i}]" for i in range(4)]
+body("mfma_f64_indep", [f"v_mfma_f64_16x16x4_f64 {ACC[i % 4]}, v[2:3], v[4:5], {ACC[i % 4]}" for i in range(16)], note="four accumulators in turn")
+body("mfma_f64_dep", [f"v_mfma_f64_16x16x4_f64 {ACC[0]}, v[2:3], v[4:5], {ACC[0]}" for i in range(16)], note="one accumulator: latency")
+body("mfma_f64_4x4", [f"v_mfma_f64_4x4x4_4b_f64 v[{64 + 2 * (i % 8)}:{65 + 2 * (i % 8)}], v[2:3], v[4:5], v[{64 + 2 * (i % 8)}:{65 + 2 * (i % 8)}]" for i in range(16)], note="4 blocks of 4x4x4 (256 fma)")
+for nf in (4, 8, 12, 16, 24):
+    mm = []
+    for i in range(8):
+        mm.append(f"v_mfma_f64_16x16x4_f64 {ACC[i % 4]}, v[2:3], v[4:5], {ACC[i % 4]}")
+        mm += [f"v_fma_f64 {d(CH[(j + nf * i) % 16])}, {d(CH[(j + nf * i) % 16])}, v[2:3], v[4:5]" for j in range(nf)]
+    body(f"mfma_f64_fma{nf}", mm, n_valu=8, note=f"1 mfma + {nf} independent v_fma_f64; cycles per (mfma + {nf} fma)")
 REPEAT = {k: 4 for k in BODIES}
 for k in ("bpermute", "fma_with_bpermute", "fma_with_lds_xchg", "fir_serial", "fir_x2", "fir_x4"): REPEAT[k] = 2
 
