@@ -787,7 +787,17 @@ __device__ __forceinline__ void ev_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#define EV3_BLK 288                          /* doubles per block: 16 rows of 16 samples + 2 pads */
+/* A block of 256 filtered samples as 16 rows of eight 16-byte units (two samples each): unit c of row r at 16-byte
+ * slot 9 r + 2 c, i.e. even rows on even slots and odd rows on the odd slots between them.  Both sides of the
+ * FIR -> DFT exchange are then conflict-free: the eight lanes the LDS serves together write unit i of eight
+ * consecutive rows (slots 9 r + 2 i: all different mod 8), and the sixteen lanes it serves together read units 0..7
+ * of the two rows 2 m1 and 2 m1 + 1 (slots {0, 2, .. 14} and 9 + {0, 2, .. 14}: all different mod 16).  Rows 18
+ * doubles apart (slot 9 r + c, rounds 2-3) served every DFT-input read in two turns: 64 of the 580 LDS cycles of a
+ * round, the whole SQ_LDS_BANK_CONFLICT count of the kernel (tools/lds_model.py).  160 slots per block keep the
+ * blocks of the four windows a multiple of 16 slots apart. */
+#define EV3_BLK 320                          /* doubles per block */
+#define EV3_ROW(r) (18 * (r))                /* first double of row r */
+#define EV3_UNIT(c) (4 * (c))                /* first double of unit c within its row */
 #define EV3_HEADS (5 * EV3_BLK)
 #define EV3_SLOTS (EV3_HEADS + 64)           /* + 4 x 16 window heads */
 #define EV3_TERMS_OFF (EV_CWAVES * EV3_SLOTS * 8)
@@ -967,11 +977,11 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
         r[4 * u + 2 * k + 1] = ok ? nrm(hi - mean) : 0.0;
       }
     }
-    double *dst = buf + base5 * EV3_BLK + (ln >> 2) * 18 + 4 * (ln & 3);
+    double *dst = buf + base5 * EV3_BLK + EV3_ROW(ln >> 2) + EV3_UNIT(2 * (ln & 3));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #define XW(m) r[i + 16 - (m)]
-      dst[i] = BL_FIR_SEL(FIR_MODE, XW, FC);
+      dst[EV3_UNIT(i >> 1) + (i & 1)] = BL_FIR_SEL(FIR_MODE, XW, FC);
 #undef XW
     }
   }
@@ -1084,21 +1094,21 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     phase(1);
     ev_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
 #pragma unroll
-    for (int i = 0; i < 16; ++i) blk_b[18 * l + i] = yv[i];
+    for (int i = 0; i < 16; ++i) blk_b[EV3_ROW(l) + EV3_UNIT(i >> 1) + (i & 1)] = yv[i];
     buf[EV3_HEADS + ln] = yh;
     ev_wave_sync();
     /* 3. DFT input of window g: lane l holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
     double re[16], im[16];
     {
-      const int off = l < 8 ? 2 * l : 2 * l + 2; /* row 2 m1' or 2 m1' + 1 of the block, 18 doubles each */
+      const int off = EV3_ROW(l >> 3) + EV3_UNIT(l & 7); /* unit l & 7 of row 2 m1' or 2 m1' + 1 of the block */
       const double *ia = blk_a + off, *ib = blk_b + off;
       const double *i0 = l < 8 ? buf + EV3_HEADS + 16 * g + 2 * l : ia;
       re[0] = i0[0];
       im[0] = i0[1];
 #pragma unroll
-      for (int m1 = 1; m1 < 8; ++m1) { re[m1] = ia[36 * m1]; im[m1] = ia[36 * m1 + 1]; }
+      for (int m1 = 1; m1 < 8; ++m1) { re[m1] = ia[EV3_ROW(2 * m1)]; im[m1] = ia[EV3_ROW(2 * m1) + 1]; }
 #pragma unroll
-      for (int m1 = 8; m1 < 16; ++m1) { re[m1] = ib[36 * (m1 - 8)]; im[m1] = ib[36 * (m1 - 8) + 1]; }
+      for (int m1 = 8; m1 < 16; ++m1) { re[m1] = ib[EV3_ROW(2 * (m1 - 8))]; im[m1] = ib[EV3_ROW(2 * (m1 - 8)) + 1]; }
     }
     ev_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
     stamp(s, 2);

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""LDS bank-conflict model for the exchange layouts of k_env_windows3 (inherited from its round-2 predecessor) (MI355X_MICROARCH.md, LDS
-section): per instruction the wave is served in fixed lane groups, one LDS cycle per group when
-conflict-free; each extra distinct address on a busy bank adds one cycle.  Prints cycles per
-wave-instruction for every pattern (ideal in brackets)."""
+"""LDS bank-conflict model for the LDS traffic of a compute wave of k_env_windows3 (MI355X_MICROARCH.md, LDS
+section): per instruction the wave is served in fixed lane groups, one LDS cycle per group when conflict-free; each
+extra distinct address on a busy bank adds one cycle.  Prints LDS cycles per round for every access pattern with the
+block layout of rounds 2-3 (rows 18 doubles apart) and the one the kernel uses since round 4 (16-byte unit c of row
+r at slot 9 r + 2 c, 160 slots per block), and searches the affine layouts slot = a r + b c for conflict-free ones.
+Checked against the counters: 64 conflict cycles per round predicted for the old layout, SQ_LDS_BANK_CONFLICT /
+rounds = 64 measured; the new one measures 0.8 % of the LDS-active cycles (profiles/r04_hbm_traffic.json).
+usage: python tools/lds_model.py [search]"""
 from itertools import product
 
 R128 = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
@@ -34,87 +38,59 @@ def cycles(kind, addr_of_lane, active=None):
     return total
 
 
-def slot(j):
-    return 18 + j + 2 * (j // 20)
+g = lambda lane: lane >> 4
+l = lambda lane: lane & 15
 
 
-def report(name, kind, fn, n_instr, active=None):
-    ideal = len(KINDS[kind][0])
-    worst = max(cycles(kind, lambda lane, i=i: fn(lane, i), active) for i in range(n_instr))
-    tot = sum(cycles(kind, lambda lane, i=i: fn(lane, i), active) for i in range(n_instr))
-    print(f"{name:<34} {kind:<10} x{n_instr:<3} total {tot:>4} LDS cycles (ideal {ideal * n_instr}), worst instr {worst}")
-    return tot
+def total(kind, fn, n, active=None):
+    return sum(cycles(kind, lambda lane, i=i: fn(lane, i), active) for i in range(n))
 
 
-def main(xrow=17, xgoff=272, prow=9, pgoff=144, trow=258):
-    g = lambda lane: lane >> 4
-    l = lambda lane: lane & 15
-    t = 0
-    t += report("z store (10 x b128 per lane)", "write_b128", lambda ln, i: 8 * (22 * ln + 18 + 2 * i), 10)
-    t += report("DFT input load (m1)", "read_b128", lambda ln, m1: 8 * slot(256 * g(ln) + 32 * m1 + 2 * l(ln)), 16)
-    t += report("xch write re/im (k1)", "write_b64", lambda ln, k1: 8 * (g(ln) * xgoff + k1 * xrow + l(ln)), 32)
-    if xrow % 2 == 0:
-        t += report("xch read (b128 pairs)", "read_b128", lambda ln, q: 8 * (g(ln) * xgoff + l(ln) * xrow + 2 * q), 16)
-    else:
-        t += report("xch read (b64)", "read_b64", lambda ln, n0: 8 * (g(ln) * xgoff + l(ln) * xrow + n0), 32)
-    t += report("partner write (k0)", "write_b64", lambda ln, q: 8 * ((q // 8) * 576 + g(ln) * pgoff + l(ln) * prow + q % 8), 16)
-
-    def pslot(ln, q):
-        k1, k0 = l(ln), q % 8
-        sl = ((16 - k1) & 15) * 8 + (7 - k0) if k1 else (8 - k0 if k0 else 0)
-        return 8 * ((q // 8) * 576 + g(ln) * pgoff + (sl >> 3) * prow + (sl & 7))
-    t += report("partner read", "read_b64", pslot, 16)
-    t += report("tw256 read (k1)", "read_b128", lambda ln, k1: 16 * ((k1 + 1) * 16 + l(ln)), 15)
-    t += report("tw512 read (k0)", "read_b128", lambda ln, k0: 16 * (l(ln) + 16 * k0), 8)
-    t += report("terms write own", "write_b64", lambda ln, k0: 8 * (g(ln) * trow + l(ln) + 16 * k0), 8)
-    t += report("terms write mirror", "write_b64", lambda ln, k0: 8 * (g(ln) * trow + 256 - l(ln) - 16 * k0), 8)
-    s = report("summing wave read (28 lanes)", "read_b128", lambda ln, q: 8 * (ln * trow + 2 * q), 128, active=lambda ln: ln < 28)
-    print(f"compute wave total {t} LDS cycles per round; summing wave {s} per tile ({s / 7:.0f} per round)")
+def fir_dft_exchange(slot_of, blk_slots, base5):
+    """LDS cycles of the FIR store (8 x b128 per lane: unit i of row l of block g + 1) and the DFT-input reads
+    (16 x b128: unit l & 7 of row 2 m1 + (l >> 3) of blocks g and g + 1) with unit c of row r at 16-byte slot
+    slot_of(r, c) of a block, blocks blk_slots apart"""
+    pa = lambda ln: (base5 + g(ln)) % 5
+    pb = lambda ln: (base5 + g(ln) + 1) % 5
+    w = total("write_b128", lambda ln, i: 16 * (pb(ln) * blk_slots + slot_of(l(ln), i)), 8)
+    ra = total("read_b128", lambda ln, m: 16 * (pa(ln) * blk_slots + slot_of(2 * m + (l(ln) >> 3), l(ln) & 7)), 8)
+    rb = total("read_b128", lambda ln, m: 16 * (pb(ln) * blk_slots + slot_of(2 * m + (l(ln) >> 3), l(ln) & 7)), 8)
+    return w, ra + rb
 
 
-if __name__ == "__main__" and "search" not in __import__("sys").argv:
-    import sys
-    kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:])}
-    main(**kw)
+def main():
+    for name, slot_of, blk in (("rows 18 doubles apart (rounds 2-3)", lambda r, c: 9 * r + c, 144),
+                               ("slot 9 r + 2 c, 160 per block (round 4)", lambda r, c: 9 * r + 2 * c, 160)):
+        w, r = max(fir_dft_exchange(slot_of, blk, b5) for b5 in range(5))
+        print(f"{name:<42} FIR store {w:>3} (ideal 64)   DFT-input reads {r:>3} (ideal 64)")
+    blk = 160 * 2  # doubles
+    rows = [
+        ("transpose write (re, im: 2 x 16 b64)", "write_b64", lambda ln, k: 8 * (g(ln) * blk + 18 * (k % 16) + l(ln)), 32, None),
+        ("transpose read (2 x 8 b128)", "read_b128", lambda ln, q: 8 * (g(ln) * blk + 18 * l(ln) + 2 * (q % 8)), 16, None),
+        ("tw512 read (8 b128)", "read_b128", lambda ln, k0: 16 * (l(ln) + 16 * k0), 8, None),
+        ("terms, first halves (8 b64)", "write_b64", lambda ln, k0: 8 * (g(ln) * 258 + l(ln) + 16 * k0), 8, None),
+        ("terms, kept second halves (8 b64)", "write_b64", lambda ln, k0: 8 * (g(ln) * 258 + 256 - l(ln) - 16 * k0), 8, None),
+        ("summing wave (65 b128, 56 lanes)", "read_b128",
+         lambda ln, q: 8 * (min(ln & 31, 27) * 258 + (0 if ln < 32 else 130) + 2 * q), 65, lambda ln: (ln & 31) < 28),
+    ]
+    for name, kind, fn, n, act in rows:
+        print(f"{name:<42} {total(kind, fn, n, act):>4} (ideal {len(KINDS[kind][0]) * n})")
 
 
 def search():
-    """brute-force layout parameters for conflict-free 16-byte accesses"""
-    g = lambda lane: lane >> 4
-    l = lambda lane: lane & 15
-    print("-- DFT input load: slot(j) = 18 + j + 2*(j//20) + woff*(j//256)")
-    for woff in range(0, 34, 2):
-        sl = lambda j: 18 + j + 2 * (j // 20) + woff * (j // 256)
-        tot = sum(cycles("read_b128", lambda ln, m1=m1: 8 * sl(256 * g(ln) + 32 * m1 + 2 * l(ln))) for m1 in range(16))
-        # z stores with the same slot function (each lane's 20 outputs may straddle a window boundary)
-        st = 0
-        for i in range(0, 20, 2):
-            st += cycles("write_b128", lambda ln, i=i: 8 * sl(20 * ln + i))
-        print(f"  woff {woff:>2}: load {tot} (ideal 64), store {st} (ideal 80)")
-    print("-- xch read as b128: row stride xrow (even), group offset xgoff")
-    best = []
-    for xrow in (16, 18, 20, 22):
-        for xgoff in range(16 * xrow, 16 * xrow + 66, 2):
-            rd = sum(cycles("read_b128", lambda ln, q=q: 8 * (g(ln) * xgoff + l(ln) * xrow + 2 * q)) for q in range(8))
-            wr = sum(cycles("write_b64", lambda ln, k1=k1: 8 * (g(ln) * xgoff + k1 * xrow + l(ln))) for k1 in range(16))
-            best.append((rd + wr, rd, wr, xrow, xgoff))
-    for b in sorted(best)[:6]:
-        print("  total %d (read %d ideal 32, write %d ideal 64) xrow %d xgoff %d" % b)
-    print("-- partner as complex b128: lane row stride prow (entries of 16 B), group offset pgoff (entries)")
-    best = []
-    for prow in (8, 9, 10, 11, 12):
-        for pgoff in range(16 * prow, 16 * prow + 34):
-            wr = sum(cycles("write_b128", lambda ln, q=q: 16 * (g(ln) * pgoff + l(ln) * prow + q)) for q in range(8))
-
-            def ps(ln, k0):
-                k1 = l(ln)
-                sl = ((16 - k1) & 15) * 8 + (7 - k0) if k1 else (8 - k0 if k0 else 0)
-                return 16 * (g(ln) * pgoff + (sl >> 3) * prow + (sl & 7))
-            rd = sum(cycles("read_b128", lambda ln, k0=k0: ps(ln, k0)) for k0 in range(8))
-            best.append((rd + wr, rd, wr, prow, pgoff))
-    for b in sorted(best)[:6]:
-        print("  total %d (read %d ideal 32, write %d ideal 64) prow %d pgoff %d" % b)
+    found = []
+    for blk in range(144, 164):
+        for a in range(1, 24):
+            for b in (1, 2, 3, 4):
+                used = {a * r + b * c for r in range(16) for c in range(8)}
+                if len(used) < 128 or max(used) >= blk:
+                    continue
+                worst = max(sum(fir_dft_exchange(lambda r, c: a * r + b * c, blk, b5)) for b5 in range(5))
+                found.append((worst, blk, a, b))
+    for worst, blk, a, b in sorted(found)[:8]:
+        print(f"slot = {a} r + {b} c, {blk} slots per block: {worst} LDS cycles per round (ideal 128)")
 
 
-if __name__ == "__main__" and "search" in __import__("sys").argv:
-    search()
+if __name__ == "__main__":
+    import sys
+    search() if "search" in sys.argv else main()
