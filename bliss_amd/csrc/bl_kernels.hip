@@ -6,9 +6,10 @@
  * (ref CMakeLists.txt:22, -std=c99) operation by operation.
  *
  * Kernels (reference code each one replaces):
- *   k_pcm_scan     sum, sum of squares, first/last non-zero index, central
- *                  histogram in one pass        ref src/helpers.c:30-49,
- *                                               src/amplitude_sort.c:26-39
+ *   k_pcm_scan     sum, sum of squares, central histogram in one pass
+ *                                               ref src/helpers.c:30-49,
+ *                                               src/amplitude_sort.c:33-39
+ *   k_trim         first / last non-zero sample  ref src/amplitude_sort.c:26-31
  *   k_song_prep    bl_mean / bl_variance values, start/end, reciprocal used by
  *                  the normalisation            ref src/tempo_atk_sort.c:101-107
  *   k_variance_wrap  exact int32-wrapping bl_variance for |mean| > 13571
@@ -70,51 +71,52 @@ __device__ __forceinline__ void bl_wave_sync() {
 /* ------------------------------------------------------------------------- */
 /* k_pcm_scan                                                                 */
 
-template <bool HIST = true>
-__device__ __forceinline__ void scan_sample(int s, unsigned idx, long long &sum,
-                                            unsigned long long &sq, unsigned &first, int &last,
-                                            unsigned *lh) {
-  sum += s;
-  sq += (unsigned)(s * s);
-  if (s != 0) {
-    first = min(first, idx);
-    last = max(last, (int)idx);
-  }
-  if (HIST) {
-    const unsigned b = (unsigned)(s + BL_HIST_BINS / 2);
-    if (b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
-  }
+/* One in-range count of the central histogram for each half of a packed word of two samples: bin = s + 2048 as
+ * a 16-bit sum (v_pk_add_u16 for both halves), byte address = base + 4 * bin (v_mad_u32_u16 takes the half it is
+ * told to), ds_add_u32.  NO range test: a sample outside [-2048, 2048) gives a bin in [4096, 65536) and an address
+ * beyond the workgroup's LDS allocation — the histogram is the LAST thing in it — and the LDS discards
+ * out-of-range writes (ISA: DS instructions, out-of-range addresses; checked on the device by
+ * tests/test_gpu_parity.py::test_histogram_out_of_range_samples_are_dropped).  4 instructions per word instead of
+ * 10 with extraction, compare and exec masks. */
+typedef __attribute__((address_space(3))) unsigned bl_lds_u32;
+__device__ __forceinline__ void scan_hist_word(unsigned w, unsigned lds_base) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  us2 v;
+  __builtin_memcpy(&v, &w, 4);
+  v += (us2){BL_HIST_BINS / 2, BL_HIST_BINS / 2};
+  unsigned b2;
+  __builtin_memcpy(&b2, &v, 4);
+  unsigned a0, a1;
+  const unsigned one = 1u;
+  asm volatile("v_mad_u32_u16 %0, %2, 4, %3 op_sel:[0,0,0,0]\n\t"
+               "v_mad_u32_u16 %1, %2, 4, %3 op_sel:[1,0,0,0]"
+               : "=&v"(a0), "=&v"(a1) : "v"(b2), "v"(lds_base));
+  asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a0), "v"(a1), "v"(one) : "memory");
 }
 
+/* sum, sum of squares and the central histogram of every song; the first / last non-zero sample is k_trim's.
+ * Per 16-byte vector (8 samples): sums through v_dot2_i32_i16 (lo + hi and lo^2 + hi^2 per word; the latter read
+ * as unsigned is exact up to 2^31), the histogram through scan_hist_word.  Two vectors per iteration keep two
+ * loads in flight per lane. */
 template <bool HIST>
 __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pcm,
                                                   const bl_dsong *__restrict__ songs,
                                                   bl_dstats *stats, unsigned *hist) {
-  __shared__ unsigned lh[BL_HIST_BINS];
+  __shared__ unsigned lh[BL_HIST_BINS]; /* the only LDS of this kernel: nothing lies behind it */
   const int tid = threadIdx.x;
   const bl_dsong sg = songs[blockIdx.y];
   const int16_t *p = pcm + sg.pcm_off;
   for (int i = tid; i < BL_HIST_BINS; i += 256) lh[i] = 0;
   __syncthreads();
+  const unsigned lds_base = (unsigned)(size_t)(bl_lds_u32 *)lh;
 
   long long sum = 0;
   unsigned long long sq = 0;
-  unsigned first = 0xFFFFFFFFu;
-  int last = -1;
   const unsigned nvec = (unsigned)sg.n >> 3;
   const uint4 *pv = reinterpret_cast<const uint4 *>(p);
-  /* Per 16-byte vector (8 samples): sums through v_dot2_i32_i16 (lo + hi and lo^2 + hi^2 per
-   * word; the latter read as unsigned is exact up to 2^31), the histogram through one LDS
-   * atomic per in-range sample.  The first / last non-zero sample can only sit in the first /
-   * last non-zero vector a thread sees (its vectors come in increasing order), so the loop
-   * just remembers those two vectors and the samples are located afterwards.  Two vectors
-   * per iteration keep two loads in flight per lane. */
   typedef short short2v __attribute__((ext_vector_type(2)));
   const short2v ones = {1, 1};
-  uint4 fq = make_uint4(0, 0, 0, 0), lq = make_uint4(0, 0, 0, 0);
-  unsigned fv = 0xFFFFFFFFu, lv = 0;
-  bool any = false;
-  auto eat = [&](const uint4 q, unsigned v) {
+  auto eat = [&](const uint4 q) {
     const unsigned w[4] = {q.x, q.y, q.z, q.w};
     int s32 = 0;
 #pragma unroll
@@ -123,64 +125,113 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pc
       __builtin_memcpy(&pr, &w[k], 4);
       s32 = __builtin_amdgcn_sdot2(pr, ones, s32, false);
       sq += (unsigned)__builtin_amdgcn_sdot2(pr, pr, 0, false);
-      if (HIST) {
-        const unsigned b0 = (unsigned)((int)(short)(w[k] & 0xFFFFu) + BL_HIST_BINS / 2);
-        const unsigned b1 = (unsigned)((int)(short)(w[k] >> 16) + BL_HIST_BINS / 2);
-        if (b0 < BL_HIST_BINS) atomicAdd(&lh[b0], 1u);
-        if (b1 < BL_HIST_BINS) atomicAdd(&lh[b1], 1u);
-      }
+      if (HIST) scan_hist_word(w[k], lds_base);
     }
     sum += s32;
-    if ((q.x | q.y | q.z | q.w) != 0u) {
-      if (!any) { any = true; fv = v; fq = q; }
-      lv = v; lq = q;
-    }
   };
   const unsigned gstride = gridDim.x * 256u;
   unsigned v = blockIdx.x * 256u + tid;
   for (; v + gstride < nvec; v += 2 * gstride) {
     const uint4 q0 = pv[v], q1 = pv[v + gstride];
-    eat(q0, v);
-    eat(q1, v + gstride);
+    eat(q0);
+    eat(q1);
   }
-  if (v < nvec) eat(pv[v], v);
-  if (any) {
-    const unsigned fw[4] = {fq.x, fq.y, fq.z, fq.w}, lw[4] = {lq.x, lq.y, lq.z, lq.w};
-#pragma unroll
-    for (int k = 3; k >= 0; --k) {
-      if (fw[k] >> 16) first = 8u * fv + 2u * k + 1u;
-      if (fw[k] & 0xFFFFu) first = 8u * fv + 2u * k;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (lw[k] & 0xFFFFu) last = (int)(8u * lv + 2u * k);
-      if (lw[k] >> 16) last = (int)(8u * lv + 2u * k + 1u);
-    }
+  if (v < nvec) eat(pv[v]);
+  if (blockIdx.x == 0 && tid < (sg.n & 7)) { /* the samples behind the last whole vector */
+    const int sv = (int)p[8u * nvec + tid];
+    sum += sv;
+    sq += (unsigned)(sv * sv);
+    const unsigned b = (unsigned)(sv + BL_HIST_BINS / 2);
+    if (HIST && b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
   }
-  if (blockIdx.x == 0 && tid < (sg.n & 7)) {
-    const unsigned idx = 8u * nvec + tid;
-    scan_sample<HIST>((int)p[idx], idx, sum, sq, first, last, lh);
-  }
-  /* wave reduction, then one set of atomics per wave */
+  /* wave reduction, then one pair of atomics per wave */
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     sum += __shfl_down(sum, off);
     sq += __shfl_down(sq, off);
-    first = min(first, (unsigned)__shfl_down((int)first, off));
-    last = max(last, __shfl_down(last, off));
   }
   bl_dstats *st = stats + blockIdx.y;
   if ((tid & 63) == 0) {
     atomicAdd(&st->sum, (unsigned long long)sum);
     atomicAdd(&st->sumsq, sq);
-    atomicMin(&st->first, first);
-    atomicMax(&st->last, last);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the inline-asm adds are invisible to hipcc's counters */
   __syncthreads();
   unsigned *gh = hist + (size_t)blockIdx.y * BL_HIST_BINS;
   for (int i = tid; i < BL_HIST_BINS; i += 256) {
     const unsigned c = lh[i];
     if (c) atomicAdd(&gh[i], c);
+  }
+}
+
+/* k_trim: the first and the last non-zero sample of every song (ref amplitude_sort.c:26-31, the two trim loops).
+ * They sit within a few thousand samples of the ends of any real recording, so this is a search, not a pass: one
+ * workgroup per song, wave 0 walks forward and wave 1 backward, 1 024 samples per step, until a vector with a
+ * non-zero sample turns up.  (Tracked inside k_pcm_scan's loop it cost 14 instructions per 8 samples.)  An
+ * all-zero song is the only one searched to the end; it is refused anyway (k_song_prep). */
+__global__ __launch_bounds__(128) void k_trim(const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
+                                              bl_dstats *stats) {
+  const bl_dsong sg = songs[blockIdx.x];
+  const int16_t *p = pcm + sg.pcm_off;
+  const uint4 *pv = reinterpret_cast<const uint4 *>(p);
+  const int lane = threadIdx.x & 63, n = sg.n;
+  const int nvec = n >> 3;
+  const bool fwd = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+  bl_dstats *st = stats + blockIdx.x;
+  /* position of the first (fwd) / last non-zero 16-bit half of a non-zero vector */
+  auto locate = [&](const uint4 q) -> int {
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+    int at = fwd ? 8 : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (fwd) {
+        if (w[3 - k] >> 16) at = 2 * (3 - k) + 1;
+        if (w[3 - k] & 0xFFFFu) at = 2 * (3 - k);
+      } else {
+        if (w[k] & 0xFFFFu) at = 2 * k;
+        if (w[k] >> 16) at = 2 * k + 1;
+      }
+    }
+    return at;
+  };
+  if (fwd) {
+    unsigned first = 0xFFFFFFFFu;
+    for (int v0 = 0; v0 < nvec; v0 += 128) {
+      const int va = v0 + lane, vb = v0 + 64 + lane;
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      const uint4 qa = va < nvec ? pv[va] : z, qb = vb < nvec ? pv[vb] : z;
+      const unsigned long long ma = __ballot((qa.x | qa.y | qa.z | qa.w) != 0u);
+      const unsigned long long mb = __ballot((qb.x | qb.y | qb.z | qb.w) != 0u);
+      if (ma | mb) {
+        const int src = ma ? __builtin_ctzll(ma) : __builtin_ctzll(mb);
+        const unsigned mine = 8u * (unsigned)(ma ? va : vb) + (unsigned)locate(ma ? qa : qb);
+        first = (unsigned)__shfl((int)mine, src);
+        break;
+      }
+    }
+    if (first == 0xFFFFFFFFu) /* nothing in the whole vectors: the up to seven samples behind them */
+      for (int i = 8 * nvec; i < n; ++i)
+        if (p[i] != 0) { first = (unsigned)i; break; }
+    if (lane == 0) st->first = first;
+  } else {
+    int last = -1;
+    for (int i = n - 1; i >= 8 * nvec; --i)
+      if (p[i] != 0) { last = i; break; }
+    if (last < 0)
+      for (int v1 = nvec; v1 > 0; v1 -= 128) { /* vectors [v1 - 128, v1) */
+        const int va = v1 - 1 - lane, vb = v1 - 65 - lane;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const uint4 qa = va >= 0 ? pv[va] : z, qb = vb >= 0 ? pv[vb] : z;
+        const unsigned long long ma = __ballot((qa.x | qa.y | qa.z | qa.w) != 0u);
+        const unsigned long long mb = __ballot((qb.x | qb.y | qb.z | qb.w) != 0u);
+        if (ma | mb) { /* lane 0 holds the highest vector of each half */
+          const int src = ma ? __builtin_ctzll(ma) : __builtin_ctzll(mb);
+          const int mine = 8 * (ma ? va : vb) + locate(ma ? qa : qb);
+          last = __shfl(mine, src);
+          break;
+        }
+      }
+    if (lane == 0) st->last = last;
   }
 }
 
@@ -1759,6 +1810,7 @@ int blk_analyze(const blk_analyze_args &a) {
     hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx_scan, n_songs), dim3(256), 0, stream, a.pcm, a.songs,
                        a.stats, a.hist);
   }
+  hipLaunchKernelGGL(k_trim, dim3(n_songs), dim3(128), 0, stream, a.pcm, a.songs, a.stats);
   hipLaunchKernelGGL(k_song_prep, dim3(tb64), dim3(64), 0, stream, a.songs, a.stats, n_songs,
                      a.results);
   hipLaunchKernelGGL(k_variance_wrap, dim3(gx_scan, n_songs), dim3(256), 0, stream, a.pcm, a.songs,
@@ -2024,6 +2076,7 @@ int blk_scan_one(hipStream_t s, const int16_t *pcm, const bl_dsong *d_songs, bl_
   BL_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * BL_HIST_BINS, s));
   hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(64), 0, s, d_stats, 1);
   hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx, 1), dim3(256), 0, s, pcm, d_songs, d_stats, d_hist);
+  hipLaunchKernelGGL(k_trim, dim3(1), dim3(128), 0, s, pcm, d_songs, d_stats);
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
 }

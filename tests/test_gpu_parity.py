@@ -367,6 +367,36 @@ def test_extreme_amplitudes(gpu_lib, oracle):
             assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= REL * max(abs(b), 1e-6), (i, k, a, b)
 
 
+def test_histogram_out_of_range_samples_are_dropped(gpu_lib, oracle):
+    """k_pcm_scan counts a sample into the central histogram without a range test: an out-of-range sample becomes an
+    LDS address beyond the workgroup's allocation, which the hardware discards (scan_hist_word).  Songs that sit on
+    the edges of the range (-2049 / -2048 / 2047 / 2048), at the ends of the 16-bit range, and just inside it, odd
+    lengths included (the samples behind the last whole vector take the tested path): `amplitude` and the histogram
+    integral bit-identical to the oracle's, `start` / `end` (k_trim) exact with silence on both sides."""
+    rng = np.random.default_rng(77)
+    n = 22050 * 2 * 6
+    edges = np.array([-32768, -2049, -2048, -2047, -1, 0, 1, 2046, 2047, 2048, 32767], dtype=np.int16)
+    songs = [
+        edges[rng.integers(0, len(edges), n)],                       # only edge values
+        rng.integers(-2048, 2048, n + 5).astype(np.int16),           # everything in range, n % 8 = 5
+        rng.integers(-32768, 32768, n + 3).astype(np.int16),         # 6 % in range
+        np.where(rng.random(n + 7) < 0.5, rng.integers(-2100, 2100, n + 7), rng.integers(-32768, 32768, n + 7)).astype(np.int16),
+    ]
+    songs[0][:1031] = 0          # leading silence ends inside a vector
+    songs[0][-2050:] = 0
+    songs[1][:8] = 0             # exactly one zero vector
+    songs[2][-3:] = 0            # the samples behind the last whole vector are the silence
+    songs[3][-9:] = 0
+    songs[3][-10] = 2048
+    got = bliss_amd.analyze_batch_host(songs, 2, 6)
+    for i, s16 in enumerate(songs):
+        ref = oracle.analyze(s16, 2, 6)
+        for k in INTS:
+            assert int(got[i][k]) == int(ref[k]), (i, k, int(got[i][k]), int(ref[k]))
+        assert np.float32(got[i]["amplitude"]) == np.float32(ref["amplitude"]), (i, "amplitude bits")
+        assert np.float32(got[i]["hist_integral"]) == np.float32(ref["hist_integral"]), (i, "histogram integral bits")
+
+
 def test_random_soak_small(gpu_lib, oracle):
     """tools/soak.py on 24 random songs (random rate / channels / level / spectrum / DC / silences): integers
     exact; tempo / amplitude / attack within 1e-4 relative (tempo and amplitude bit-identical); frequency and
