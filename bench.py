@@ -2,7 +2,7 @@
 """bench.py — throughput of the bliss analysis hot path on MI355X.
 
 One *step* = one pass of the hot path over one resident batch of synthetic decoded
-songs: pcm_scan -> amplitude / frequency / envelope kernels -> force vectors
+songs: frequency pass with the statistics riding along -> envelope / amplitude kernels -> force vectors
 (bl_analyze after decode, ref src/analyze.c:40-80), then — as BASELINE.json's
 batch-of-songs mode asks — an all-gather of the 16-byte force vectors over RCCL and this
 rank's row block of the bl_distance matrix (ref src/analyze.c:96-100).
@@ -203,8 +203,8 @@ def _committed_profile(songs, song_samples):
         psongs = tj.get("songs") or 0
         if tk.get("SQ_INSTS_VALU") and psongs:
             out["valu_instr_per_window"] = tk["SQ_INSTS_VALU"] / (psongs * 62012.0)
-        step = [kernels[k]["hbm_bytes"] for k in ("k_pcm_scan", "k_env_windows3", "k_freq_frames", "k_amp_finish",
-                                                  "k_env_tail") if k in kernels and "hbm_bytes" in kernels[k]]
+        step = [kernels[k]["hbm_bytes"] for k in ("k_pcm_scan", "k_freq_scan", "k_trim", "k_env_windows3", "k_freq_frames",
+                                                  "k_amp_finish", "k_env_tail") if k in kernels and "hbm_bytes" in kernels[k]]
         if step and tj.get("algorithmic_bytes_per_launch"):
             out["whole_step_traffic_ratio"] = sum(step) / tj["algorithmic_bytes_per_launch"]
     except (OSError, KeyError, ValueError, TypeError) as e:
@@ -449,7 +449,7 @@ def main():
 
     # per-kernel device time of the timed region (HIP events on the launch stream)
     kern = {}
-    for name in ("pcm_scan", "amp_finish", "freq_frames", "freq_finish", "env_windows", "env_tail",
+    for name in ("pcm_scan", "freq_scan", "amp_finish", "freq_frames", "freq_finish", "env_windows", "env_tail",
                  "distance"):
         n = C.c_int(0)
         ms = lib.bl_amd_profile_ms(name.encode(), C.byref(n))

@@ -431,10 +431,14 @@ __global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__
  */
 typedef bl_c2<bl_f2> c2p; /* a complex number per frame of the pair */
 
-#define BL_FREQ_XCH_BYTES (16 * BL_FFT_XCH_ELEMS * 16)
-#define BL_FREQ_ACC_OFF (BL_FREQ_XCH_BYTES + 2 * 256 * 8 + 512 * 4)
-#define BL_FREQ_LDS_BYTES (BL_FREQ_ACC_OFF + 256 * 4 + 64)
-#define BL_FREQ_FPI 32 /* frames per workgroup iteration */
+/* LDS of a workgroup of W waves: 4 W exchange buffers, twiddles + Hann, the running spectrum + relay word, and —
+ * k_freq_scan only — the central histogram, LAST (scan_hist_word relies on nothing lying behind it) */
+#define BL_FREQ_XCH_BYTES(W) (4 * (W) * BL_FFT_XCH_ELEMS * 16)
+#define BL_FREQ_ACC_OFF(W) (BL_FREQ_XCH_BYTES(W) + 2 * 256 * 8 + 512 * 4)
+#define BL_FREQ_HIST_OFF(W) (BL_FREQ_ACC_OFF(W) + 256 * 4 + 64)
+#define BL_FREQ_LDS_BYTES BL_FREQ_HIST_OFF(4)                                 /* k_freq_frames: 76.9 KB */
+#define BL_FREQ_SCAN_WAVES 8
+#define BL_FREQ_SCAN_LDS_BYTES (BL_FREQ_HIST_OFF(BL_FREQ_SCAN_WAVES) + 4 * BL_HIST_BINS) /* k_freq_scan: 159.1 KB */
 /* row stride of the power staging: 2 rows = 16 banks (mod 32) apart, so the two 16-lane groups
  * that share a 32-lane store group land on disjoint banks */
 #define BL_FREQ_SROW 264
@@ -453,27 +457,40 @@ template <int CTRL> __device__ __forceinline__ bl_f2 bl_dpp_f2_old(bl_f2 old, bl
   return (bl_f2){__int_as_float(x), __int_as_float(y)};
 }
 
-template <bool STEREO>
+/* WAVES waves per workgroup (one workgroup per song).  SCAN: the statistics pass rides along — every PCM word the
+ * transform loads also goes into the song's sum, sum of squares and central histogram (k_pcm_scan's arithmetic),
+ * so the analysis reads the PCM twice instead of three times. */
+template <bool STEREO, int WAVES, bool SCAN>
 __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm, const bl_dsong &sg,
-                                                 const bl_tables &tb, float *spectrum) {
+                                                 const bl_tables &tb, float *spectrum, bl_dstats *st,
+                                                 unsigned *gh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  c2p *xch = reinterpret_cast<c2p *>(smem); /* 16 x 272 */
-  c2f *tw256 = reinterpret_cast<c2f *>(smem + BL_FREQ_XCH_BYTES);
+  constexpr int FPI = 8 * WAVES; /* frames per workgroup iteration */
+  c2p *xch = reinterpret_cast<c2p *>(smem); /* 4 WAVES x 272 */
+  c2f *tw256 = reinterpret_cast<c2f *>(smem + BL_FREQ_XCH_BYTES(WAVES));
   c2f *tw512 = tw256 + 256;
   float *hann = reinterpret_cast<float *>(tw512 + 256);
-  float *accv = reinterpret_cast<float *>(smem + BL_FREQ_ACC_OFF); /* ps[0..255] so far */
+  float *accv = reinterpret_cast<float *>(smem + BL_FREQ_ACC_OFF(WAVES)); /* ps[0..255] so far */
+  unsigned *lh = reinterpret_cast<unsigned *>(smem + BL_FREQ_HIST_OFF(WAVES)); /* SCAN: the histogram */
   typedef __attribute__((address_space(3))) volatile int lds_vint;
-  lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF + 256 * 4);
+  lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF(WAVES) + 256 * 4);
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, gl = g & 3;
   const int16_t *p = pcm + sg.pcm_off;
-  tw256[tid] = tb.tw256_f[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
-  tw512[tid] = tb.tw512_f[tid];
-  hann[tid] = tb.hann[tid];
-  hann[tid + 256] = tb.hann[tid + 256];
-  accv[tid] = 0.f;
+  if (WAVES == 4 || tid < 256) {
+    tw256[tid] = tb.tw256_f[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
+    tw512[tid] = tb.tw512_f[tid];
+    hann[tid] = tb.hann[tid];
+    hann[tid + 256] = tb.hann[tid + 256];
+    accv[tid] = 0.f;
+  }
+  if (SCAN)
+    for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) lh[i] = 0;
   if (tid == 0) relay[0] = 0;
   __syncthreads();
+  const unsigned lds_hist = (unsigned)(size_t)(bl_lds_u32 *)lh;
+  long long sum = 0;
+  unsigned long long sq = 0;
 
   c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* the transpose buffer of this 16-lane group */
   float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [8][BL_FREQ_SROW] */
@@ -529,22 +546,47 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
   c2f w1[W1_REGS];
 #pragma unroll
   for (int k1 = 1; k1 < W1_REGS; ++k1) w1[k1] = tw256[k1 * 16 + l];
-  const int n_iter = (sg.n_frames + BL_FREQ_FPI - 1) / BL_FREQ_FPI;
+  const int n_iter = (sg.n_frames + FPI - 1) / FPI;
 #pragma unroll
   for (int part = 0; part < 4; ++part) fetch(8 * wave + 2 * gl, part);
   for (int it = 0; it < n_iter; ++it) {
-    const int f = it * BL_FREQ_FPI + 8 * wave + 2 * gl;
+    const int f = it * FPI + 8 * wave + 2 * gl;
     bl_f2 re[16], im[16];
+    /* SCAN: the statistics of every word as the transform's input stage consumes it (its registers die here).  The
+     * frames of a song's last iteration that lie beyond its end (their loads were clamped onto the last frame) are
+     * not counted. */
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    const short2v ones = {1, 1};
+    int s32 = 0;
+    auto word = [&](unsigned w) {
+      short2v pr;
+      __builtin_memcpy(&pr, &w, 4);
+      s32 = __builtin_amdgcn_sdot2(pr, ones, s32, false);
+      sq += (unsigned)__builtin_amdgcn_sdot2(pr, pr, 0, false);
+      scan_hist_word(w, lds_hist);
+    };
+    const bool full = it + 1 < n_iter; /* wave-uniform */
+    const bool va = f < sg.n_frames, vb = f + 1 < sg.n_frames;
 #pragma unroll
     for (int m1 = 0; m1 < 16; ++m1) {
       const int d = 32 * m1 + 2 * l;
       bl_f2 r, i;
+      if (SCAN) {
+        if (full) {
+          word(pa[m1].x); word(pb[m1].x);
+          if (stereo) { word(pa[m1].y); word(pb[m1].y); }
+        } else {
+          if (va) { word(pa[m1].x); if (stereo) word(pa[m1].y); }
+          if (vb) { word(pb[m1].x); if (stereo) word(pb[m1].y); }
+        }
+      }
       mono2(pa[m1], pb[m1], r, i);
       const bl_f2 h = *reinterpret_cast<const bl_f2 *>(hann + d); /* hann[d], hann[d + 1] */
       re[m1] = r * (bl_f2){h.x, h.x};
       im[m1] = i * (bl_f2){h.y, h.y};
     }
-    fetch(f + BL_FREQ_FPI, 0);
+    if (SCAN) sum += s32;
+    fetch(f + FPI, 0);
     /* the exchange buffers of a 16-lane group are private to it, hence to its wave */
     bl_fft16(re, im);
 #pragma unroll
@@ -559,16 +601,16 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
       gx[k1 * 17 + l] = v;
     }
     bl_wave_sync();
-    fetch(f + BL_FREQ_FPI, 1);
+    fetch(f + FPI, 1);
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) {
       const c2p v = gx[l * 17 + n0];
       re[n0] = v.re; im[n0] = v.im;
     }
     bl_wave_sync();
-    fetch(f + BL_FREQ_FPI, 2);
+    fetch(f + FPI, 2);
     bl_fft16(re, im);
-    fetch(f + BL_FREQ_FPI, 3);
+    fetch(f + FPI, 3);
     /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16,
      * fetched by a mirror of the 16-lane row and a shift by one (DPP), not through LDS; lane 0
      * is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
@@ -598,9 +640,9 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     if (l == 0) { sa[128] = mid.x; sb[128] = mid.y; }
     bl_wave_sync();
     /* the baton: frames 32 it + 8 w .. + 7 join the running spectrum after those of wave w - 1 */
-    const int turn = 4 * it + wave;
+    const int turn = WAVES * it + wave;
     /* frames beyond the song's last one (their loads were clamped onto it) are not added */
-    const int n_live = sg.n_frames - (it * BL_FREQ_FPI + 8 * wave);
+    const int n_live = sg.n_frames - (it * FPI + 8 * wave);
     /* this wave's 8 x 4 power values per lane are fetched BEFORE it asks for the baton (they are
      * its own), all 32 reads in flight at once; holding the baton then costs one read of the
      * running spectrum, eight dependent adds and a write.  (Reading them one by one behind the
@@ -640,8 +682,30 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     bl_wave_sync();
     if (lane == 0) relay[0] = turn + 1;
   }
+  if (SCAN) {
+    /* the samples behind the last whole frame (fewer than 512 per channel) */
+    for (int i = sg.n_frames * 512 * sg.channels + tid; i < sg.n; i += 64 * WAVES) {
+      const int sv = (int)p[i];
+      sum += sv;
+      sq += (unsigned)(sv * sv);
+      const unsigned b = (unsigned)(sv + BL_HIST_BINS / 2);
+      if (b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sum += __shfl_down(sum, off);
+      sq += __shfl_down(sq, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&st->sum, (unsigned long long)sum);
+      atomicAdd(&st->sumsq, sq);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the inline-asm adds are invisible to hipcc's counters */
+  }
   __syncthreads();
-  spectrum[(size_t)blockIdx.x * 256 + tid] = accv[tid];
+  if (WAVES == 4 || tid < 256) spectrum[(size_t)blockIdx.x * 256 + tid] = accv[tid];
+  if (SCAN)
+    for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) gh[i] = lh[i]; /* the workgroup owns the song: plain stores */
 }
 
 /* one workgroup per song; the channel count is uniform per workgroup, so the branch costs one
@@ -650,8 +714,21 @@ __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restric
                                                         const bl_dsong *__restrict__ songs,
                                                         bl_tables tb, float *spectrum) {
   const bl_dsong sg = songs[blockIdx.x];
-  if (sg.channels == 2) freq_frames_body<true>(pcm, sg, tb, spectrum);
-  else freq_frames_body<false>(pcm, sg, tb, spectrum);
+  if (sg.channels == 2) freq_frames_body<true, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
+  else freq_frames_body<false, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
+}
+
+/* k_freq_scan: k_freq_frames and k_pcm_scan in one pass over the PCM — one 512-thread workgroup per song and CU
+ * (the same eight waves per CU as two k_freq_frames workgroups, one histogram) */
+__global__ __launch_bounds__(64 * BL_FREQ_SCAN_WAVES) void k_freq_scan(const int16_t *__restrict__ pcm,
+                                                                       const bl_dsong *__restrict__ songs,
+                                                                       bl_tables tb, float *spectrum,
+                                                                       bl_dstats *stats, unsigned *hist) {
+  const bl_dsong sg = songs[blockIdx.x];
+  bl_dstats *st = stats + blockIdx.x;
+  unsigned *gh = hist + (size_t)blockIdx.x * BL_HIST_BINS;
+  if (sg.channels == 2) freq_frames_body<true, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
+  else freq_frames_body<false, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
 }
 
 __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ spectrum,
@@ -1712,6 +1789,8 @@ int blk_configure_device(void) {
 #endif
   BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_frames),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_freq_scan),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, BL_FREQ_SCAN_LDS_BYTES));
   return BL_OK;
 }
 
@@ -1802,10 +1881,20 @@ int blk_analyze(const blk_analyze_args &a) {
   const int n_songs = a.n_songs, what = a.what;
   hipStream_t stream = a.stream;
   const int gx_scan = grid_x_for(((long long)a.max_n / 8 + 255) / 256, n_songs, 8, a.n_cu);
-  BL_HIP_CHECK(hipMemsetAsync(a.hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
   const int tb64 = (n_songs + 63) / 64;
   hipLaunchKernelGGL(k_stats_init, dim3(tb64), dim3(64), 0, stream, a.stats, n_songs);
-  {
+  /* With all three analyzers asked for, the statistics ride along with the frequency pass (k_freq_scan): two
+   * passes over the PCM instead of three.  A measurement build can take them apart again (BL_AMD_FUSED_SCAN=0). */
+  bool fused = what == 7;
+#ifdef BL_AMD_MEASURE
+  if (const char *e = getenv("BL_AMD_FUSED_SCAN")) fused = fused && atoi(e) != 0;
+#endif
+  if (fused) {
+    Mark m(a.mark, a.mark_user, PK_FREQ_SCAN, stream);
+    hipLaunchKernelGGL(k_freq_scan, dim3(n_songs), dim3(64 * BL_FREQ_SCAN_WAVES), BL_FREQ_SCAN_LDS_BYTES, stream,
+                       a.pcm, a.songs, a.tb, a.spectrum, a.stats, a.hist);
+  } else {
+    BL_HIP_CHECK(hipMemsetAsync(a.hist, 0, sizeof(unsigned) * BL_HIST_BINS * (size_t)n_songs, stream));
     Mark m(a.mark, a.mark_user, PK_SCAN, stream);
     hipLaunchKernelGGL(k_pcm_scan<true>, dim3(gx_scan, n_songs), dim3(256), 0, stream, a.pcm, a.songs,
                        a.stats, a.hist);
@@ -1892,7 +1981,7 @@ int blk_analyze(const blk_analyze_args &a) {
                        a.results);
   }
   if (what & 2) {
-    {
+    if (!fused) {
       Mark m(a.mark, a.mark_user, PK_FREQ, stream);
       hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream, a.pcm,
                          a.songs, a.tb, a.spectrum);

@@ -57,7 +57,7 @@ struct bl_tables {
 
 /* ---- per-kernel timing (bench.py's roofline leg) ---------------------------- */
 
-enum { PK_SCAN, PK_AMP, PK_FREQ, PK_FREQ_FIN, PK_ENV, PK_TAIL, PK_DIST, PK_COUNT };
+enum { PK_SCAN, PK_AMP, PK_FREQ, PK_FREQ_FIN, PK_ENV, PK_TAIL, PK_DIST, PK_FREQ_SCAN, PK_COUNT };
 
 /* called by the launchers around a kernel when profiling is on: begin = 1 before the
  * launch, 0 after it, on the stream the kernel is launched on */

@@ -730,7 +730,7 @@ void bl_amd_profile_reset(void) {
 
 double bl_amd_profile_ms(const char *name, int *launches) {
   static const char *const kProfNames[PK_COUNT] = {"pcm_scan",    "amp_finish", "freq_frames", "freq_finish",
-                                                   "env_windows", "env_tail",   "distance"};
+                                                   "env_windows", "env_tail",   "distance",    "freq_scan"};
   if (launches) *launches = 0;
   bl_amd_ctx *c = blr_default_ctx();
   if (!c || !name) return -1.0;

@@ -42,7 +42,7 @@ def main():
     lib.bl_amd_profile(0)
     import ctypes as C
     kern = {}
-    for name in ("pcm_scan", "amp_finish", "freq_frames", "env_windows", "env_tail"):
+    for name in ("pcm_scan", "freq_scan", "amp_finish", "freq_frames", "env_windows", "env_tail"):
         n = C.c_int(0)
         ms = lib.bl_amd_profile_ms(name.encode(), C.byref(n))
         kern[name] = round(ms / a.steps, 2)   # per batch: a mixed batch launches the window and tail kernels twice
@@ -55,7 +55,7 @@ def main():
                       "kernels_ms_per_batch": kern,
                       # what the batch takes beyond the kernels of the main stream: the part of the serial envelope
                       # tail (side stream) that nothing hides, plus the small kernels and launch gaps
-                      "ms_beyond_main_stream_kernels": round(dt * 1e3 - sum(kern[k] for k in ("pcm_scan", "amp_finish", "freq_frames", "env_windows")), 1),
+                      "ms_beyond_main_stream_kernels": round(dt * 1e3 - sum(kern[k] for k in ("pcm_scan", "freq_scan", "amp_finish", "freq_frames", "env_windows")), 1),
                       "status_ok": bool(np.all(res["status"] == 0))}))
 
 
