@@ -94,6 +94,21 @@ __device__ __forceinline__ void scan_hist_word(unsigned w, unsigned lds_base) {
   asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a0), "v"(a1), "v"(one) : "memory");
 }
 
+/* Everything the statistics take from one packed word of two samples: lo + hi into the 32-bit partial sum
+ * (v_dot2_i32_i16 with ones), lo^2 + hi^2 (the same instruction; <= 2^31, read as unsigned) into the 64-bit sum of
+ * squares by ONE v_mad_u64_u32 (r * 1 + sq; a 64-bit add is two instructions and every one of these issues in four
+ * cycles: tools/gen_ubench_issue.py), and the histogram counts: 6 instructions per word. */
+__device__ __forceinline__ void scan_word(unsigned w, int &s32, unsigned long long &sq, unsigned lds_hist, bool hist) {
+  typedef short short2v __attribute__((ext_vector_type(2)));
+  const short2v ones = {1, 1};
+  short2v pr;
+  __builtin_memcpy(&pr, &w, 4);
+  s32 = __builtin_amdgcn_sdot2(pr, ones, s32, false);
+  const unsigned r = (unsigned)__builtin_amdgcn_sdot2(pr, pr, 0, false);
+  asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(sq) : "v"(r) : "vcc");
+  if (hist) scan_hist_word(w, lds_hist);
+}
+
 /* sum, sum of squares and the central histogram of every song; the first / last non-zero sample is k_trim's.
  * Per 16-byte vector (8 samples): sums through v_dot2_i32_i16 (lo + hi and lo^2 + hi^2 per word; the latter read
  * as unsigned is exact up to 2^31), the histogram through scan_hist_word.  Two vectors per iteration keep two
@@ -114,19 +129,11 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pc
   unsigned long long sq = 0;
   const unsigned nvec = (unsigned)sg.n >> 3;
   const uint4 *pv = reinterpret_cast<const uint4 *>(p);
-  typedef short short2v __attribute__((ext_vector_type(2)));
-  const short2v ones = {1, 1};
   auto eat = [&](const uint4 q) {
     const unsigned w[4] = {q.x, q.y, q.z, q.w};
     int s32 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      short2v pr;
-      __builtin_memcpy(&pr, &w[k], 4);
-      s32 = __builtin_amdgcn_sdot2(pr, ones, s32, false);
-      sq += (unsigned)__builtin_amdgcn_sdot2(pr, pr, 0, false);
-      if (HIST) scan_hist_word(w[k], lds_base);
-    }
+    for (int k = 0; k < 4; ++k) scan_word(w[k], s32, sq, lds_base, HIST);
     sum += s32;
   };
   const unsigned gstride = gridDim.x * 256u;
@@ -555,16 +562,8 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     /* SCAN: the statistics of every word as the transform's input stage consumes it (its registers die here).  The
      * frames of a song's last iteration that lie beyond its end (their loads were clamped onto the last frame) are
      * not counted. */
-    typedef short short2v __attribute__((ext_vector_type(2)));
-    const short2v ones = {1, 1};
     int s32 = 0;
-    auto word = [&](unsigned w) {
-      short2v pr;
-      __builtin_memcpy(&pr, &w, 4);
-      s32 = __builtin_amdgcn_sdot2(pr, ones, s32, false);
-      sq += (unsigned)__builtin_amdgcn_sdot2(pr, pr, 0, false);
-      scan_hist_word(w, lds_hist);
-    };
+    auto word = [&](unsigned w) { scan_word(w, s32, sq, lds_hist, true); };
     const bool full = it + 1 < n_iter; /* wave-uniform */
     const bool va = f < sg.n_frames, vb = f + 1 < sg.n_frames;
 #pragma unroll

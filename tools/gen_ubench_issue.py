@@ -112,6 +112,16 @@ for nf in (4, 8, 12, 16, 24):
         mm.append(f"v_mfma_f64_16x16x4_f64 {ACC[i % 4]}, v[2:3], v[4:5], {ACC[i % 4]}")
         mm += [f"v_fma_f64 {d(CH[(j + nf * i) % 16])}, {d(CH[(j + nf * i) % 16])}, v[2:3], v[4:5]" for j in range(nf)]
     body(f"mfma_f64_fma{nf}", mm, n_valu=8, note=f"1 mfma + {nf} independent v_fma_f64; cycles per (mfma + {nf} fma)")
+# the integer instructions of the statistics pass (scan_hist_word, the v_dot2 sums)
+body("mad_u32_u16", [f"v_mad_u32_u16 v{64 + (i % 32)}, v{32 + (i % 32)}, 4, v6 op_sel:[{i % 2},0,0,0]" for i in range(64)], note="extract a half, * 4, + base")
+body("dot2_i32_i16", [f"v_dot2_i32_i16 v{64 + (i % 32)}, v{32 + (i % 32)}, v{32 + (i % 32)}, v{64 + (i % 32)}" for i in range(64)], note="lo*lo + hi*hi + acc")
+body("pk_add_u16", [f"v_pk_add_u16 v{64 + (i % 32)}, v{32 + (i % 32)}, v6" for i in range(64)])
+body("pk_fma_f32", [f"v_pk_fma_f32 {d(64 + 2 * (i % 16))}, {d(32 + 2 * (i % 16))}, v[2:3], {d(64 + 2 * (i % 16))}" for i in range(64)], note="two f32 fma per lane")
+body("lshl_add_u32", [f"v_lshl_add_u32 v{64 + (i % 32)}, v{32 + (i % 32)}, 2, v6" for i in range(64)])
+body("bfe_u32", [f"v_bfe_u32 v{64 + (i % 32)}, v{32 + (i % 32)}, 16, 16" for i in range(64)])
+body("mad_u64_u32", [f"v_mad_u64_u32 v[{64 + 2 * (i % 16)}:{65 + 2 * (i % 16)}], vcc, v{32 + (i % 32)}, v6, v[{64 + 2 * (i % 16)}:{65 + 2 * (i % 16)}]" for i in range(64)], note="32 x 32 + 64 -> 64")
+body("add3_u32", [f"v_add3_u32 v{64 + (i % 32)}, v{32 + (i % 32)}, v6, v{64 + (i % 32)}" for i in range(64)])
+body("addc_u64", [x for i in range(32) for x in (f"v_add_co_u32 v{64 + 2 * (i % 16)}, vcc, v{64 + 2 * (i % 16)}, v6", f"v_addc_co_u32 v{65 + 2 * (i % 16)}, vcc, 0, v{65 + 2 * (i % 16)}, vcc")], note="64-bit add as add_co + addc")
 REPEAT = {k: 4 for k in BODIES}
 for k in ("bpermute", "fma_with_bpermute", "fma_with_lds_xchg", "fir_serial", "fir_x2", "fir_x4"): REPEAT[k] = 2
 
