@@ -397,6 +397,36 @@ def test_histogram_out_of_range_samples_are_dropped(gpu_lib, oracle):
         assert np.float32(got[i]["hist_integral"]) == np.float32(ref["hist_integral"]), (i, "histogram integral bits")
 
 
+def test_fused_statistics_pass_equals_the_separate_kernels(gpu_lib, oracle):
+    """bl_analyze / the batch calls run k_freq_scan (statistics riding along with the frequency pass); the single
+    analyzers of the reference's API (bl_amplitude_sort, bl_frequency_sort, bl_envelope_sort: ref
+    python/bliss/bl_song.py:179-199) run k_pcm_scan and k_freq_frames.  Same bits from both, on mono and stereo
+    buffers whose lengths leave every kind of remainder (behind the last frame, behind the last 16-byte vector) and
+    with silence at both ends (k_trim)."""
+    cases = [(31, 22050, 2, 7, 0), (32, 22050, 1, 9, 333), (33, 44100, 2, 3, 1022), (34, 11025, 1, 5, 7)]
+    songs, chans = [], []
+    for seed, rate, ch, secs, extra in cases:
+        pcm = oracle.synth(seed, rate, ch, rate * ch * secs + extra)
+        pcm[:100 + seed] = 0
+        pcm[-(50 + seed):] = 0
+        songs.append(pcm)
+        chans.append(ch)
+    got = bliss_amd.analyze_batch_host(songs, chans, 5)
+    for i, pcm in enumerate(songs):
+        song = _lib.BlSong()
+        song.sample_array = pcm.ctypes.data
+        song.channels, song.nSamples, song.sample_rate = chans[i], len(pcm), 22050
+        song.nb_bytes_per_sample, song.duration = 2, 5
+        amp = gpu_lib.bl_amplitude_sort(C.byref(song))
+        frq = gpu_lib.bl_frequency_sort(C.byref(song))
+        env = _lib.EnvelopeResult()
+        gpu_lib.bl_envelope_sort(C.byref(song), C.byref(env))
+        assert np.float32(amp) == np.float32(got[i]["amplitude"]), (i, "amplitude")
+        assert np.float32(frq) == np.float32(got[i]["frequency"]), (i, "frequency")
+        assert np.float32(env.tempo) == np.float32(got[i]["tempo"]) and np.float32(env.attack) == np.float32(got[i]["attack"]), i
+        check_song(got[i], oracle.analyze(pcm, chans[i], 5), f"case {i}")
+
+
 def test_random_soak_small(gpu_lib, oracle):
     """tools/soak.py on 24 random songs (random rate / channels / level / spectrum / DC / silences): integers
     exact; tempo / amplitude / attack within 1e-4 relative (tempo and amplitude bit-identical); frequency and
