@@ -18,6 +18,6 @@ for r in csv.DictReader(open(sys.argv[1])):
     k=r['Kernel_Name'].split('(')[0][:40]
     acc[(k,r['Counter_Name'])]+=float(r['Counter_Value'])
 for (k,c),v in sorted(acc.items()):
-    if 'env_windows' in k or 'freq_frames' in k or 'pcm_scan' in k: print(f"{k:42s} {c:28s} {v:.6g}")
+    if 'env_windows' in k or 'freq_' in k or 'pcm_scan' in k: print(f"{k:42s} {c:28s} {v:.6g}")
 PY
 done

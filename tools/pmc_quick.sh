@@ -2,7 +2,7 @@
 # Per-kernel SQ counters of one bench step (separate --pmc passes, --kernel-trace only), printed as a table.
 # usage (through gpurun): tools/pmc_quick.sh <songs> [kernel-name-substring ...]
 SONGS=${1:-2048}; shift
-PAT=${*:-freq_frames env_windows pcm_scan}
+PAT=${*:-freq_scan freq_frames env_windows pcm_scan}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmcq
 rm -rf $OUT; mkdir -p $OUT
