@@ -410,31 +410,33 @@ __global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_freq_frames                                                              */
-
+/* k_freq_frames / k_freq_scan                                                */
 
 /*
- * k_freq_frames: Hann window + 512-point f32 real DFT + per-bin power, summed over the frames in
- * the reference's order (ref src/frequency_sort.c:67-94).
+ * Hann window + 512-point f32 real DFT + per-bin power, summed over the frames in the reference's order
+ * (ref src/frequency_sort.c:67-94).  k_freq_frames is the frequency analysis alone (four waves per workgroup);
+ * k_freq_scan is the same body with eight waves and the statistics pass riding along (see freq_frames_body) —
+ * what bl_analyze and the batch calls launch.
  *
  * One workgroup per song.  Every 16-lane group transforms TWO frames at once: all values are
  * 2-vectors (frame A in .x, frame B in .y), so the whole transform is v_pk_add / v_pk_mul /
  * v_pk_fma_f32 on register pairs with no shuffling between the halves — twice the f32 rate of
  * the scalar VALU for the same instruction count (the one-frame-per-group kernel spent 40 % of
  * its VALU stream on v_mov's that re-paired (re, im) for the packed instructions hipcc formed).
- * A wave covers 8 consecutive frames per iteration, the four waves 32.
+ * A wave covers 8 consecutive frames per iteration, the WAVES waves 8 * WAVES.
  *
  * ref :88-93 adds every frame's power spectrum into one f32 accumulator per bin, frame after
  * frame; f32 addition does not associate, so the order is part of the result (15 000 frames
  * leave ~1e-5 of room in `frequency`).  The running spectrum goes round the waves like a baton:
- * wave w waits for the relay word to reach 4 * it + w, adds its eight frames bin by bin in frame
+ * wave w waits for the relay word to reach WAVES * it + w, adds its eight frames bin by bin in frame
  * order (its own power values re-laid out through its private exchange space: lane j owns bins
  * j, j + 64, j + 128, j + 192) and passes it on.  No workgroup barrier in the loop; the waves
- * stagger themselves by a quarter iteration.
+ * stagger themselves.
  *
- * LDS: 16 exchange buffers of 272 (re, im) 2-vectors (16 bytes each: every exchange access is a
- * b128), twiddles, Hann, the running spectrum, the relay word: 76.9 KB -> two workgroups per CU,
- * two waves per SIMD (the kernel wants ~200 VGPRs: 64 for the data, 64 for the frames in flight).
+ * LDS: 4 WAVES exchange buffers of 272 (re, im) 2-vectors (16 bytes each: every exchange access is a
+ * b128), twiddles, Hann, the running spectrum, the relay word: 76.9 KB for four waves -> two workgroups per
+ * CU; 159.1 KB for eight waves with the histogram behind them -> one.  Either way two waves per SIMD (the
+ * kernel wants ~200 VGPRs: 64 for the data, 64 for the frames in flight).
  */
 typedef bl_c2<bl_f2> c2p; /* a complex number per frame of the pair */
 
@@ -1906,8 +1908,11 @@ int blk_analyze(const blk_analyze_args &a) {
   hipLaunchKernelGGL(k_variance_wrap_finish, dim3(tb64), dim3(64), 0, stream, a.songs, a.stats,
                      n_songs, a.results);
   /* Order: the envelope windows first, then the serial envelope tail on an internal side
-   * stream while the main stream runs the frequency and amplitude kernels (the tail is one
-   * latency-bound wave per 64 songs and leaves the chip free); k_force joins the two. */
+   * stream while the main stream runs the amplitude kernel (and, when the statistics were not fused into it, the
+   * frequency pass): the tail is three latency-bound waves per 64 songs and leaves the chip free; k_force joins
+   * the two.  In the fused order ~6 ms of the tail have nothing beside them; the amplitude kernel in front of or
+   * beside the window kernel instead, or the last songs in a window launch of their own, measured slower
+   * (DESIGN.md Appendix A). */
   bool tail_async = false;
   if (what & 4) {
     const int fir_mode = blk_fir_mode();
@@ -1970,7 +1975,7 @@ int blk_analyze(const blk_analyze_args &a) {
     }
     if (tail_async) BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
   }
-  /* The short amplitude kernel goes before the wide frequency pass: the tail's 143 KB
+  /* The short amplitude kernel goes before the wide frequency pass (where there is one): the tail's 143 KB
    * workgroups only reach a CU when the dispatcher has no pending frequency workgroup to put
    * there, so they have to be resident before that pass begins (launched after it, the tail
    * started ~60 ms late and ~10 ms of it were exposed per 8 192 songs). */
