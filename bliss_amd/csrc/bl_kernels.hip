@@ -1907,13 +1907,17 @@ int blk_analyze(const blk_analyze_args &a) {
                      a.stats);
   hipLaunchKernelGGL(k_variance_wrap_finish, dim3(tb64), dim3(64), 0, stream, a.songs, a.stats,
                      n_songs, a.results);
-  /* Order: the envelope windows first, then the serial envelope tail on an internal side
-   * stream while the main stream runs the amplitude kernel (and, when the statistics were not fused into it, the
-   * frequency pass): the tail is three latency-bound waves per 64 songs and leaves the chip free; k_force joins
-   * the two.  In the fused order ~6 ms of the tail have nothing beside them; the amplitude kernel in front of or
-   * beside the window kernel instead, or the last songs in a window launch of their own, measured slower
-   * (DESIGN.md Appendix A). */
+  /* Order: the envelope windows first, then the serial envelope tail (three latency-bound waves per 64 songs: it
+   * leaves the chip free) beside what is left — the amplitude kernel and, when the statistics were not fused into
+   * it, the frequency pass; k_force joins the two.  The tail's 143 KB workgroups only reach a CU when the dispatcher
+   * has nothing else pending for it, so they have to be resident BEFORE the kernels they run beside begin:
+   *   fused    the tail follows the window kernel on the main stream; amplitude and frequency finish go to the side
+   *            stream behind an event (353.9 -> 349.9 ms per 8 192 songs: launched the other way round the
+   *            amplitude kernel took the CUs first and the tail ran after it, not beside it);
+   *   separate the tail goes to the side stream, the main stream runs the short amplitude kernel and then the wide
+   *            frequency pass (launched after that pass, the tail started ~60 ms late). */
   bool tail_async = false;
+  hipStream_t rest_stream = stream; /* where the amplitude kernel and the frequency finish go */
   if (what & 4) {
     const int fir_mode = blk_fir_mode();
     /* one 512-thread workgroup per CU; the blocks of a song split its rounds of four windows
@@ -1947,9 +1951,15 @@ int blk_analyze(const blk_analyze_args &a) {
     /* the serial tail of the songs [first, first + count), on the side stream when there is something to
      * overlap it with */
     const bool side = (what & 3) && a.side;
-    auto launch_tail = [&](int first, int count) -> int {
+    auto launch_tail = [&](int first, int count, bool last) -> int {
       hipStream_t ts = stream;
-      if (side) {
+      if (side && fused && last) {
+        /* the tail stays here; the rest waits on the side stream for the window kernel in front of it */
+        BL_HIP_CHECK(hipEventRecord(a.ev_env, stream));
+        BL_HIP_CHECK(hipStreamWaitEvent(a.side, a.ev_env, 0));
+        rest_stream = a.side;
+        tail_async = true;
+      } else if (side) {
         BL_HIP_CHECK(hipEventRecord(a.ev_env, stream));
         BL_HIP_CHECK(hipStreamWaitEvent(a.side, a.ev_env, 0));
         ts = a.side;
@@ -1966,35 +1976,34 @@ int blk_analyze(const blk_analyze_args &a) {
      * under the window kernel of the rest. */
     const int n_head = (a.n_head > 0 && a.n_head < n_songs && side) ? a.n_head : 0;
     if (n_head) {
-      if (launch_env(0, n_head, a.max_n) != BL_OK || launch_tail(0, n_head) != BL_OK) return BL_UNEXPECTED;
+      if (launch_env(0, n_head, a.max_n) != BL_OK || launch_tail(0, n_head, false) != BL_OK) return BL_UNEXPECTED;
       if (launch_env(n_head, n_songs - n_head, a.max_n_rest) != BL_OK ||
-          launch_tail(n_head, n_songs - n_head) != BL_OK)
+          launch_tail(n_head, n_songs - n_head, true) != BL_OK)
         return BL_UNEXPECTED;
     } else {
-      if (launch_env(0, n_songs, a.max_n) != BL_OK || launch_tail(0, n_songs) != BL_OK) return BL_UNEXPECTED;
+      if (launch_env(0, n_songs, a.max_n) != BL_OK || launch_tail(0, n_songs, true) != BL_OK) return BL_UNEXPECTED;
     }
-    if (tail_async) BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
   }
-  /* The short amplitude kernel goes before the wide frequency pass (where there is one): the tail's 143 KB
-   * workgroups only reach a CU when the dispatcher has no pending frequency workgroup to put
-   * there, so they have to be resident before that pass begins (launched after it, the tail
-   * started ~60 ms late and ~10 ms of it were exposed per 8 192 songs). */
   if (what & 1) {
-    Mark m(a.mark, a.mark_user, PK_AMP, stream);
-    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, stream, a.songs, a.stats, a.hist,
+    Mark m(a.mark, a.mark_user, PK_AMP, rest_stream);
+    hipLaunchKernelGGL(k_amp_finish, dim3(n_songs), dim3(256), 0, rest_stream, a.songs, a.stats, a.hist,
                        a.results);
   }
   if (what & 2) {
     if (!fused) {
-      Mark m(a.mark, a.mark_user, PK_FREQ, stream);
-      hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, stream, a.pcm,
+      Mark m(a.mark, a.mark_user, PK_FREQ, rest_stream);
+      hipLaunchKernelGGL(k_freq_frames, dim3(n_songs), dim3(256), BL_FREQ_LDS_BYTES, rest_stream, a.pcm,
                          a.songs, a.tb, a.spectrum);
     }
-    Mark m(a.mark, a.mark_user, PK_FREQ_FIN, stream);
-    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, stream, a.spectrum, a.songs,
+    Mark m(a.mark, a.mark_user, PK_FREQ_FIN, rest_stream);
+    hipLaunchKernelGGL(k_freq_finish, dim3(n_songs), dim3(256), 0, rest_stream, a.spectrum, a.songs,
                        a.results);
   }
-  if (tail_async) BL_HIP_CHECK(hipStreamWaitEvent(stream, a.ev_tail, 0));
+  /* whatever ran on the side stream (tails, or the amplitude / frequency finish) joins the main stream here */
+  if (tail_async) {
+    BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
+    BL_HIP_CHECK(hipStreamWaitEvent(stream, a.ev_tail, 0));
+  }
   if (what == 7) hipLaunchKernelGGL(k_force, dim3(tb64), dim3(64), 0, stream, a.results, n_songs);
   BL_HIP_CHECK(hipGetLastError());
   return BL_OK;
