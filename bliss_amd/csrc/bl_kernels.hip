@@ -88,10 +88,13 @@ __device__ __forceinline__ void scan_hist_word(unsigned w, unsigned lds_base) {
   __builtin_memcpy(&b2, &v, 4);
   unsigned a0, a1;
   const unsigned one = 1u;
+  /* one statement: between two of them hipcc pads with s_nop for hazards it cannot rule out; in this order every
+   * address has an instruction between its computation and its use */
   asm volatile("v_mad_u32_u16 %0, %2, 4, %3 op_sel:[0,0,0,0]\n\t"
-               "v_mad_u32_u16 %1, %2, 4, %3 op_sel:[1,0,0,0]"
-               : "=&v"(a0), "=&v"(a1) : "v"(b2), "v"(lds_base));
-  asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a0), "v"(a1), "v"(one) : "memory");
+               "v_mad_u32_u16 %1, %2, 4, %3 op_sel:[1,0,0,0]\n\t"
+               "ds_add_u32 %0, %4\n\t"
+               "ds_add_u32 %1, %4"
+               : "=&v"(a0), "=&v"(a1) : "v"(b2), "v"(lds_base), "v"(one) : "memory");
 }
 
 /* Everything the statistics take from one packed word of two samples: lo + hi into the 32-bit partial sum
@@ -104,7 +107,8 @@ __device__ __forceinline__ void scan_word(unsigned w, int &s32, unsigned long lo
   short2v pr;
   __builtin_memcpy(&pr, &w, 4);
   s32 = __builtin_amdgcn_sdot2(pr, ones, s32, false);
-  const unsigned r = (unsigned)__builtin_amdgcn_sdot2(pr, pr, 0, false);
+  unsigned r; /* the builtin with a zero addend becomes v_mov 0 + v_dot2c: one instruction too many */
+  asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(r) : "v"(w));
   asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(sq) : "v"(r) : "vcc");
   if (hist) scan_hist_word(w, lds_hist);
 }
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pc
   const int16_t *p = pcm + sg.pcm_off;
   for (int i = tid; i < BL_HIST_BINS; i += 256) lh[i] = 0;
   __syncthreads();
-  const unsigned lds_base = (unsigned)(size_t)(bl_lds_u32 *)lh;
+  unsigned lds_base = (unsigned)(size_t)(bl_lds_u32 *)lh;
+  asm volatile("" : "+v"(lds_base)); /* lives in a VGPR: as a scalar it is copied in front of every use */
 
   long long sum = 0;
   unsigned long long sq = 0;
@@ -497,7 +502,8 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) lh[i] = 0;
   if (tid == 0) relay[0] = 0;
   __syncthreads();
-  const unsigned lds_hist = (unsigned)(size_t)(bl_lds_u32 *)lh;
+  unsigned lds_hist = (unsigned)(size_t)(bl_lds_u32 *)lh;
+  asm volatile("" : "+v"(lds_hist)); /* lives in a VGPR: as a scalar it is copied in front of every use */
   long long sum = 0;
   unsigned long long sq = 0;
 
