@@ -397,6 +397,29 @@ def test_histogram_out_of_range_samples_are_dropped(gpu_lib, oracle):
         assert np.float32(got[i]["hist_integral"]) == np.float32(ref["hist_integral"]), (i, "histogram integral bits")
 
 
+def test_trim_search_edges(gpu_lib, oracle):
+    """k_trim finds the first / last non-zero sample by a search from both ends (ref src/amplitude_sort.c:26-31):
+    the sample at index 0, the very last one when it lies behind the last whole 16-byte vector, silence longer than
+    several search steps on either side, and a single non-zero sample (first == last)."""
+    rng = np.random.default_rng(5)
+    n = 22050 * 2 * 3 + 5
+    base = rng.integers(-9000, 9000, n).astype(np.int16)
+    base[base == 0] = 7
+    songs = []
+    a = base.copy(); songs.append(a)                                  # non-zero from index 0 to n - 1
+    b = base.copy(); b[:5000] = 0; b[-7000:] = 0; songs.append(b)      # several search steps of silence on both sides
+    c = base.copy(); c[:n - 3] = 0; c[n - 3] = 0; c[n - 2] = 12000; c[n - 1] = 0; songs.append(c)  # one sample, behind the last vector
+    d = np.zeros(n, dtype=np.int16); d[0] = -15000; d[n - 1] = 9000; songs.append(d)               # both ends only
+    e = np.zeros(n, dtype=np.int16); e[4097] = 20000; songs.append(e)                              # one sample in the middle
+    got = bliss_amd.analyze_batch_host(songs, 2, 3)
+    for i, pcm in enumerate(songs):
+        ref = oracle.analyze(pcm, 2, 3)
+        for k in ("start", "end", "mean", "variance"):
+            assert int(got[i][k]) == int(ref[k]), (i, k, int(got[i][k]), int(ref[k]))
+    assert int(got[2]["start"]) == n - 2 and int(got[2]["end"]) == n - 2
+    assert int(got[3]["start"]) == 0 and int(got[3]["end"]) == n - 1
+
+
 def test_fused_statistics_pass_equals_the_separate_kernels(gpu_lib, oracle):
     """bl_analyze / the batch calls run k_freq_scan (statistics riding along with the frequency pass); the single
     analyzers of the reference's API (bl_amplitude_sort, bl_frequency_sort, bl_envelope_sort: ref
