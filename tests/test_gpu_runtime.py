@@ -145,7 +145,7 @@ np.save(sys.argv[1] + ".len.npy", np.stack([lengths, chans]))
 
 def test_measurement_switches_are_ignored_by_the_product_build(tmp_path):
     """The result-invalidating measurement aids (BL_AMD_SQRT_VARIANT=3: the distance kernel's store stream alone,
-    BL_AMD_NO_SIDE, and the round-3 switches BL_AMD_ENV_DBG / BL_AMD_ENV_OLD, whose code is gone) only exist in `make measure` builds
+    BL_AMD_NO_SIDE, BL_AMD_FUSED_SCAN, and the round-3 switches BL_AMD_ENV_DBG / BL_AMD_ENV_OLD, whose code is gone) only exist in `make measure` builds
     (-DBL_AMD_MEASURE); the shipped library must give the same records, window energies and distance matrix
     whether those variables are set or not."""
     code = r'''
@@ -174,7 +174,8 @@ d = bliss_amd.distance_matrix(vecs)
 print(n, hashlib.md5(np.concatenate(valid).tobytes()).hexdigest(), hashlib.md5(np.ascontiguousarray(d).tobytes()).hexdigest())
 ''' % ROOT
     outs = {}
-    switches = {"BL_AMD_SQRT_VARIANT": "3", "BL_AMD_ENV_DBG": "3", "BL_AMD_ENV_OLD": "1", "BL_AMD_NO_SIDE": "1"}
+    switches = {"BL_AMD_SQRT_VARIANT": "3", "BL_AMD_ENV_DBG": "3", "BL_AMD_ENV_OLD": "1", "BL_AMD_NO_SIDE": "1",
+                "BL_AMD_FUSED_SCAN": "0"}
     for tag, env in (("plain", {}), ("switches", switches)):
         f = str(tmp_path / f"{tag}.npy")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), text=True,
