@@ -566,6 +566,11 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
   for (int part = 0; part < 4; ++part) fetch(8 * wave + 2 * gl, part);
   for (int it = 0; it < n_iter; ++it) {
     const int f = it * FPI + 8 * wave + 2 * gl;
+    /* SCAN: the input stage with the statistics (a third of the iteration's instructions and all of its LDS
+     * atomics) runs at priority 3, the first transform pass at 2, the rest at 0: of the two waves of a SIMD the one
+     * that is feeding the LDS wins the VALU.  32.6 vs 33.8 ms per 4 096 songs; the other orders (later phases
+     * first, as in k_env_windows3) made no difference, and k_freq_frames gains nothing from any (Appendix A). */
+    if (SCAN) __builtin_amdgcn_s_setprio(3);
     bl_f2 re[16], im[16];
     /* SCAN: the statistics of every word as the transform's input stage consumes it (its registers die here).  The
      * frames of a song's last iteration that lie beyond its end (their loads were clamped onto the last frame) are
@@ -595,6 +600,7 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     if (SCAN) sum += s32;
     fetch(f + FPI, 0);
     /* the exchange buffers of a 16-lane group are private to it, hence to its wave */
+    if (SCAN) __builtin_amdgcn_s_setprio(2);
     bl_fft16(re, im);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
@@ -616,6 +622,7 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     }
     bl_wave_sync();
     fetch(f + FPI, 2);
+    if (SCAN) __builtin_amdgcn_s_setprio(0);
     bl_fft16(re, im);
     fetch(f + FPI, 3);
     /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16,
