@@ -885,10 +885,12 @@ __device__ __forceinline__ double bl_norm(int k, double rcp, double rcp_lo) {
  * Two compute waves that share a SIMD and are held in step by the tile hand-over therefore do not share it: the
  * older one runs its round and waits, the younger one then runs alone with every LDS round trip of its own
  * exposed, and the tile waits for it.  PRIO gives every phase of a round a priority (4 bits per phase, phase 0 in
- * the lowest digit); the shipped table 0x222111 runs the second half of a round (transposes, second DFT pass,
- * hand-over, power terms) at 2 and the first at 1: whichever wave is further along — the one the tile is waiting
- * for — wins, whatever its age.  278 vs 306 ms per 8 192 S180 songs with identical results
- * (profiles/r04_env_variants.json).
+ * the lowest digit); the shipped table 0x222011 runs the second half of a round (transposes, second DFT pass,
+ * hand-over, power terms) at 2, normalise + FIR and the FIR -> DFT exchange at 1 and the first DFT pass at 0:
+ * whichever wave is further along — the one the tile is waiting for — wins, whatever its age.  278 vs 306 ms per
+ * 8 192 S180 songs with identical results for 0x222111 (profiles/r04_env_variants.json);
+ * the first pass at 0 another 1.0-1.3 % (three sweeps of five rounds; every table with that digit at 0 and the
+ * second half at 2 or 3 did the same).
  */
 #define EV_CWAVES 7
 #define EV_TILE (4 * EV_CWAVES)             /* windows per tile */
@@ -951,10 +953,10 @@ __device__ __forceinline__ void ev_wave_sync() {
 #define EV_PROBE_ROUNDS 16
 #define EV_PROBE_SLOTS 12
 #ifndef BL_ENV_PRIO
-#define BL_ENV_PRIO 0x222111 /* the priority table the product launches */
+#define BL_ENV_PRIO 0x222011 /* the priority table the product launches */
 #endif
 /* the priority tables the measurement build instantiates beside it (tools/env_ab.py) */
-#define EV_PRIO_TABS(X) X(0x000000) X(0x111111) X(0x322110) X(0x321000) X(0x222110) X(0x222011) X(0x232111) X(0x222112)
+#define EV_PRIO_TABS(X) X(0x000000) X(0x111111) X(0x322110) X(0x321000) X(0x222110) X(0x222111) X(0x232011) X(0x222112)
 /* PROBE (measurement builds): s_memtime stamps of one workgroup's phases into `probe` */
 template <int FIR_MODE, int PRIO, bool PROBE>
 __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(

@@ -4,8 +4,8 @@ corpus analysed with every table, results compared field by field with the shipp
 HIP events, and — for --probe tables — the s_memtime stamps of workgroup (0, 0) summarised per wave: where a
 compute wave's round goes (arithmetic phases, exchange phases, the wait in front of the hand-over).
 A table is six hex digits, one priority (0..3) per phase, phase 0 in the lowest digit; the measurement build
-instantiates the ones of EV_PRIO_TABS (bl_kernels.hip) beside the shipped 222111.  Prints one JSON object.
-usage: python tools/env_ab.py [--songs 1024] [--seconds 180] [--tabs 000000,111111,322110] [--probe 222111] [--reps 3]"""
+instantiates the ones of EV_PRIO_TABS (bl_kernels.hip) beside the shipped 222011.  Prints one JSON object.
+usage: python tools/env_ab.py [--songs 1024] [--seconds 180] [--tabs 000000,111111,322110] [--probe 222011] [--reps 3]"""
 import argparse
 import ctypes as C
 import json
@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--songs", type=int, default=1024)
     ap.add_argument("--seconds", type=int, default=180)
-    ap.add_argument("--tabs", default="000000,111111,322110,321000,222110,222011,232111,222112")
+    ap.add_argument("--tabs", default="000000,111111,322110,321000,222110,222111,232011,222112")
     ap.add_argument("--probe", default="")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=3)
