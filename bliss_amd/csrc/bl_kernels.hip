@@ -1289,7 +1289,10 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
      * go out between the arithmetic instead of in one burst. */
     stamp(s, 5);
     phase(5);
-    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
+    /* polled without s_sleep: the LDS round trip paces the loop, and a sleep quantum (64 cycles) behind the summing
+     * wave's release is 0.5 % of the kernel (35.8 vs 36.0 ms per 1 024 songs, three rounds; the summing wave's own
+     * poll and the other waits keep theirs: without it they measured the same or slower) */
+    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) {}
     ev_lds_acquire();
     stamp(s, 6);
 #pragma unroll
