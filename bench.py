@@ -573,7 +573,13 @@ def main():
                                   "what": "static: the f64 operations the arithmetic of this FIR mode needs per "
                                           "window (DESIGN.md section 4.1) at the measured f64 issue rate"},
                     "secondary_f64_valu": valu,
-                    "whole_step_traffic_ratio": prof.get("whole_step_traffic_ratio")}
+                    "whole_step_traffic_ratio": prof.get("whole_step_traffic_ratio"),
+                    # the other pass over the PCM: the frequency analysis with the statistics riding along
+                    "other_pcm_pass": ({"kernel": "k_freq_scan", "ms_avg_launch": kern["freq_scan"]["ms_avg"],
+                                        "achieved": launch_bytes / (1e-3 * kern["freq_scan"]["ms_avg"]) / 1e9,
+                                        "unit": "GB/s", "frac": launch_bytes / (1e-3 * kern["freq_scan"]["ms_avg"]) / 1e9
+                                        / HBM_PEAK_GBS, "bound": "issue (DESIGN.md section 4.4)"}
+                                       if kern.get("freq_scan", {}).get("ms_avg") else None)}
         whole_path_gbs = value / world * alg_bytes_song / 1e9
 
         # BASELINE config 4: standalone 10 000 x 10 000 bl_distance matrix on one GPU
