@@ -859,7 +859,7 @@ __device__ __forceinline__ double bl_norm(int k, double rcp, double rcp_lo) {
 /* ------------------------------------------------------------------------- */
 /* k_env_windows3: normalise + FIR + DFT + ordered sum, wave-autonomous        */
 /*
- * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, ~230 VGPRs), no workgroup
+ * One workgroup per CU: 7 compute waves + 1 summing wave (2 waves per SIMD, 213-220 VGPRs), no workgroup
  * barrier inside the loop.
  *
  * A compute wave walks a CONTIGUOUS run of rounds of four windows (one window per 16-lane group; the song's
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
   auto nrm = [&](int k) -> double { return FIR_MODE == 2 ? (double)k : bl_norm(k, rcp, rcp_lo); };
   const int r0 = run_begin(u0 + wave), r1 = run_begin(u0 + wave + 1);
   /* pass-1 twiddles kept in registers, the rest read from LDS in the round: modes 0 / 1 have room for 12
-   * (221 VGPRs); mode 2 needs fewer registers for the FIR and takes all 15 (232 VGPRs, no spill; 1 % faster) */
+   * (220 VGPRs); mode 2 needs fewer registers for the FIR and takes all 15 (213 VGPRs, no spill; 1 % faster) */
   constexpr int EV3_W1_REGS = FIR_MODE == 2 ? 16 : 13;
   c2d w1r[EV3_W1_REGS];
 #pragma unroll
