@@ -33,7 +33,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <type_traits>
 
 #include "bl_launch.h"
 #include "bl_cos.h"
@@ -956,11 +955,8 @@ __device__ __forceinline__ void ev_wave_sync() {
 #ifndef BL_ENV_PRIO
 #define BL_ENV_PRIO 0x222011 /* the priority table the product launches */
 #endif
-#ifndef BL_ENV_W7
-#define BL_ENV_W7 3 /* k_env_windows4: the summing wave runs one round of its own every BL_ENV_W7 steps */
-#endif
 /* the priority tables the measurement build instantiates beside it (tools/env_ab.py) */
-#define EV_PRIO_TABS(X) X(0x0222011) X(0x1222011) X(0x2222011) X(0x3222011) X(0x0000000) X(0x0222111)
+#define EV_PRIO_TABS(X) X(0x000000) X(0x111111) X(0x322110) X(0x321000) X(0x222110) X(0x222111) X(0x232011) X(0x222112)
 /* PROBE (measurement builds): s_memtime stamps of one workgroup's phases into `probe` */
 template <int FIR_MODE, int PRIO, bool PROBE>
 __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
@@ -1333,471 +1329,6 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
     if (ln == 0) flags[wave] = seq;
     stamp(s, 7);
     base5 = base5 == 0 ? 4 : base5 - 1; /* (4 (rho + 1)) mod 5 */
-  }
-  ++seq; /* the second halves of the last round: one more publication, nothing else in it */
-  publish_held_only();
-  if (ln == 0) flags[wave] = seq;
-}
-#undef FC
-
-/* ------------------------------------------------------------------------- */
-/* k_env_windows4: k_env_windows3 with the summing wave as an eighth, half-rate unit */
-/*
- * k_env_windows3 leaves one SIMD of every CU a third idle: SIMDs 0-2 carry two compute waves each, SIMD 3 one
- * compute wave and the summing wave (390 of a round's 977 instructions per step).  Every attempt to give the
- * lock-stepped compute waves uneven shares failed (the tile waits for its slowest wave).
- * Here the seven compute waves are left exactly as they were, and the SUMMING WAVE runs rounds of its own in the
- * time between two of its passes, at the lowest priority (it only takes issue slots its SIMD's compute wave leaves
- * free): one round every W7 steps, a third of it per step — normalise + FIR, then DFT inputs + first pass +
- * transposes, then second pass + power terms — so that a workgroup finishes 7 W7 + 1 rounds every W7 steps
- * instead of 7 W7.  It hands its terms over to nobody but itself: rows 28-31 of the hand-over area, whole rows at
- * once (no second halves kept in registers), summed by lanes 28-31 (first halves, the step after) and 60-63 (second
- * halves, the step after that), which the tile of 28 windows left idle.  No flag, no wait, no new dependency
- * between waves.
- *
- * LDS: an eighth ring slice and four more rows do not fit beside 320-double blocks.  The blocks are 288 doubles
- * again (16 rows 18 doubles apart: the DFT-input reads are served in two turns, 64 LDS cycles per round,
- * tools/lds_model.py), the 4 x 16 zero-state heads live in the two pad doubles behind the rows of the window's
- * first block, half of the W512 table that nothing reads is gone, and of the W256 table only what FIR modes 0 / 1
- * do not keep in registers: 8 x 11 520 (slices) + 32 x 2 064 (rows) + 2 048 + 768 + 144 = 161 168 bytes.
- *
- * The song's rounds are split over the units of its workgroups by weight: compute waves W7, the summing wave 1
- * (W7 = 0: a pure summing wave, the round-4 behaviour on the new layout, kept for A/B in measurement builds).
- */
-#define EV4_UNITS 8
-#define EV4_ROWS 32
-#define EV4_BLK 288                          /* doubles per block */
-#define EV4_ROW(r) (18 * (r))
-#define EV4_UNIT(c) (2 * (c))
-#define EV4_HEAD(h) (18 * ((h) >> 1) + 16 + ((h) & 1)) /* head h of a window: the pad behind row h / 2 of its first block */
-#define EV4_SLOTS (5 * EV4_BLK)
-#define EV4_TERMS_OFF (EV4_UNITS * EV4_SLOTS * 8)
-#define EV4_TW512_OFF (EV4_TERMS_OFF + EV4_ROWS * EV_TROW * 8)
-#define EV4_TW256_OFF (EV4_TW512_OFF + 128 * 16)      /* W512^k, k = 0..127 */
-#define EV4_FLAG_OFF (EV4_TW256_OFF + 3 * 16 * 16)    /* W256 rows k1 = 13..15 (FIR modes 0 / 1) */
-#define EV4_ZERO_OFF (EV4_FLAG_OFF + 128)
-#define EV4_LDS_BYTES (EV4_ZERO_OFF + 16)
-static_assert(EV4_LDS_BYTES <= 160 * 1024, "k_env_windows4: LDS");
-
-/* PRIO: digits 0..5 as in k_env_windows3; digit 6 = the priority of the summing wave's own rounds */
-template <int FIR_MODE, int PRIO, bool PROBE, int W7>
-__global__ __launch_bounds__(64 * EV4_UNITS) void k_env_windows4(
-    const int16_t *__restrict__ pcm, const bl_dsong *__restrict__ songs,
-    const bl_dstats *__restrict__ stats, bl_tables tb, float *energies, double *lc, long long *probe) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *terms = reinterpret_cast<double *>(smem + EV4_TERMS_OFF); /* [EV4_ROWS][258] */
-  c2d *tw512 = reinterpret_cast<c2d *>(smem + EV4_TW512_OFF);
-  c2d *tw256x = reinterpret_cast<c2d *>(smem + EV4_TW256_OFF);
-  typedef __attribute__((address_space(3))) volatile int lds_vint;
-  lds_vint *flags = (lds_vint *)(smem + EV4_FLAG_OFF); /* [0..6] published by the compute waves, [8] by the summing wave */
-
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, g = ln >> 4, l = ln & 15;
-  const bool probing = PROBE && blockIdx.x == 0 && blockIdx.y == 0 && probe != nullptr;
-  auto stamp = [&](int round, int slot) {
-    if (PROBE) {
-      __builtin_amdgcn_sched_barrier(0); /* no arithmetic moves across a stamp */
-      if (probing && round < EV_PROBE_ROUNDS && ln == 0)
-        probe[(wave * EV_PROBE_ROUNDS + round) * EV_PROBE_SLOTS + slot] = (long long)__builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  const bl_dsong sg = songs[blockIdx.y];
-  const bl_dstats st = stats[blockIdx.y];
-  const int16_t *p = pcm + sg.pcm_off;
-  constexpr int EV4_W1_REGS = FIR_MODE == 2 ? 16 : 13; /* pass-1 twiddle rows kept in registers (k_env_windows3) */
-  if (tid < 128) tw512[tid] = tb.tw512_d[tid];
-  if (FIR_MODE != 2 && tid >= 128 && tid < 176) tw256x[tid - 128] = tb.tw256_d[((tid & 15) * (13 + ((tid - 128) >> 4))) & 255];
-  if (tid >= 192 && tid < 228) flags[tid - 192] = 0; /* the sequence words and the zero pair behind them */
-  if (tid >= 256 && tid < 256 + EV4_ROWS) terms[(tid - 256) * EV_TROW + 257] = 0.0; /* the pad behind term 256 is read as a term */
-  __syncthreads();
-
-  /* rounds of four windows, split over the units of the song's workgroups by weight */
-  const int n_rounds = (sg.n_windows + 3) / 4;
-  constexpr int WCMP = W7 ? W7 : 1;                /* weight of a compute wave */
-  constexpr int WSUM = WCMP * EV_CWAVES + (W7 ? 1 : 0);
-  const long long wtot = (long long)WSUM * (long long)gridDim.x;
-  auto run_begin = [&](int c) -> int { /* unit c of this workgroup; c = 8: the end of its last unit */
-    const int cw = c < EV4_UNITS ? WCMP * c : WSUM;
-    return (int)((long long)n_rounds * ((long long)WSUM * (long long)blockIdx.x + cw) / wtot);
-  };
-  int steps = 0;
-  for (int c = 0; c < EV_CWAVES; ++c) steps = max(steps, run_begin(c + 1) - run_begin(c));
-  const int n7 = W7 ? run_begin(EV4_UNITS) - run_begin(EV_CWAVES) : 0;
-  const int n_used = 256 * (sg.n_windows + 1);
-  int seq = 0;
-
-  /* ---- what every unit that runs rounds needs ---- */
-  auto phase = [&](int k) {
-    const int pr = (PRIO >> (4 * k)) & 3;
-    if (pr == 0) __builtin_amdgcn_s_setprio(0);
-    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-  };
-  double *buf = reinterpret_cast<double *>(smem) + wave * EV4_SLOTS;
-  const int mean = st.mean;
-  const double rcp = st.rcp, rcp_lo = st.rcp_lo;
-#define FC(m) st.firc[m]
-  auto nrm = [&](int k) -> double { return FIR_MODE == 2 ? (double)k : bl_norm(k, rcp, rcp_lo); };
-  const int r0 = run_begin(wave), r1 = run_begin(wave + 1);
-  c2d w1r[EV4_W1_REGS];
-  int base5 = (4 * r0) % 5; /* ring position of block 4 rho, the block shared with the previous round */
-  uint4 pre[4];
-  short preh;
-  const int last8 = max(n_used - 8, 0);
-  auto fetch = [&](int rho_) {
-    const int base = 1024 * rho_ + 240 + 16 * ln; /* first input = first output - 16 */
-#pragma unroll
-    for (int u = 0; u < 4; ++u) pre[u] = *reinterpret_cast<const uint4 *>(p + min(base + 8 * u, last8));
-    preh = p[min(1024 * rho_ + 256 * g + l, n_used - 1)];
-  };
-  /* before the first round of a run: the pass-1 twiddles, the block the round cannot inherit (samples
-   * [1024 r0, 1024 r0 + 256)), the first round's samples */
-  auto run_prologue = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int k1 = 1; k1 < EV4_W1_REGS; ++k1) {
-      w1r[k1] = tb.tw256_d[(k1 * l) & 255];
-      asm volatile("" : "+v"(w1r[k1].re), "+v"(w1r[k1].im));
-    }
-    if (r0 < r1) {
-      const int s0 = 1024 * r0 + 4 * ln; /* this lane's 4 outputs; inputs [s0 - 16, s0 + 4) */
-      double r[20];
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        const int i0 = s0 - 16 + 4 * u;
-        const bool ok = i0 >= 0 && i0 + 4 <= n_used;
-        const uint2 v = *reinterpret_cast<const uint2 *>(p + (ok ? i0 : 0));
-        const unsigned w[2] = {ok ? v.x : 0u, ok ? v.y : 0u};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-          r[4 * u + 2 * k] = ok ? nrm(lo - mean) : 0.0;
-          r[4 * u + 2 * k + 1] = ok ? nrm(hi - mean) : 0.0;
-        }
-      }
-      double *dst = buf + base5 * EV4_BLK + EV4_ROW(ln >> 2) + EV4_UNIT(2 * (ln & 3));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#define XW(m) r[i + 16 - (m)]
-        dst[i] = BL_FIR_SEL(FIR_MODE, XW, FC);
-#undef XW
-      }
-    }
-    fetch(r0);
-  };
-
-  /* First half of a round (phases 0-1 of k_env_windows3): normalise (ref :109-114) the 32 samples this lane loaded,
-   * fetch the next round's, FIR (ref :123-138) outputs 16 ln .. 16 ln + 15 of the round's 1 024 new samples and the
-   * zero-state head of sample l of window g, all of it into the ring.  BG: the summing wave's own rounds — no
-   * phase priorities, no stamps. */
-  auto stage_fir = [&](int s, int rho, auto bg) __attribute__((always_inline)) {
-    constexpr bool BG = decltype(bg)::value;
-    if (!BG) { stamp(s, 0); phase(0); }
-    double yv[16], yh;
-    {
-      double r[32];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned w[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int lo = (int)(short)(w[k] & 0xFFFFu), hi = (int)(short)(w[k] >> 16);
-          r[8 * u + 2 * k] = nrm(lo - mean);
-          r[8 * u + 2 * k + 1] = nrm(hi - mean);
-        }
-      }
-      const int kh = (int)preh - mean; /* this round's head sample: fetch() below overwrites preh */
-      const double xh = nrm(kh);
-      fetch(rho + 1); /* next round's samples */
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-#define XR(m) r[i + 16 - (m)]
-        yv[i] = BL_FIR_SEL(FIR_MODE, XR, FC);
-#undef XR
-      }
-      /* zero-state heads of the four windows (ref :121): see k_env_windows3 */
-      if (FIR_MODE == 2) {
-#define KH(m) __builtin_amdgcn_update_dpp(0, kh, 0x110 + (m), 0xF, 0xF, true) /* row_shr:m, 0 when there is no lane */
-        const double p0 = (double)kh; /* tap 16 lies before the window: zero */
-        const double p1 = (double)(KH(1) + KH(15)), p2 = (double)(KH(2) + KH(14)), p3 = (double)(KH(3) + KH(13));
-        const double p4 = (double)(KH(4) + KH(12)), p5 = (double)(KH(5) + KH(11)), p6 = (double)(KH(6) + KH(10));
-        const double p7 = (double)(KH(7) + KH(9)), p8 = (double)KH(8);
-#undef KH
-        double y_ = FC(7) * p7;
-        y_ = __builtin_fma(FC(6), p6, y_);
-        y_ = __builtin_fma(FC(5), p5, y_);
-        y_ = __builtin_fma(FC(4), p4, y_);
-        y_ = __builtin_fma(FC(3), p3, y_);
-        y_ = __builtin_fma(FC(2), p2, y_);
-        y_ = __builtin_fma(FC(1), p1, y_);
-        y_ = __builtin_fma(p8, FC(8), y_);
-        yh = __builtin_fma(FC(0), p0, y_);
-      } else {
-        double hx[17];
-        hx[0] = xh;
-        hx[1] = bl_dpp_f64<0x111>(xh);  hx[2] = bl_dpp_f64<0x112>(xh);  hx[3] = bl_dpp_f64<0x113>(xh);
-        hx[4] = bl_dpp_f64<0x114>(xh);  hx[5] = bl_dpp_f64<0x115>(xh);  hx[6] = bl_dpp_f64<0x116>(xh);
-        hx[7] = bl_dpp_f64<0x117>(xh);  hx[8] = bl_dpp_f64<0x118>(xh);  hx[9] = bl_dpp_f64<0x119>(xh);
-        hx[10] = bl_dpp_f64<0x11A>(xh); hx[11] = bl_dpp_f64<0x11B>(xh); hx[12] = bl_dpp_f64<0x11C>(xh);
-        hx[13] = bl_dpp_f64<0x11D>(xh); hx[14] = bl_dpp_f64<0x11E>(xh); hx[15] = bl_dpp_f64<0x11F>(xh);
-        hx[16] = 0.0;
-#define XH(m) hx[m]
-        yh = BL_FIR_SEL(FIR_MODE, XH, FC);
-#undef XH
-      }
-    }
-    /* ring positions: window g reads block g (first half) and block g + 1 (second half); the lanes of group g have
-     * just filtered block g + 1 */
-    const int xa = base5 + g, xb = xa + 1;
-    const int pa = xa >= 5 ? xa - 5 : xa, pb = xb >= 5 ? xb - 5 : xb;
-    double *blk_a = buf + pa * EV4_BLK, *blk_b = buf + pb * EV4_BLK;
-    if (!BG) { stamp(s, 1); phase(1); }
-    ev_wave_sync(); /* previous round's LDS reads (DFT exchanges) are complete */
-#pragma unroll
-    for (int i = 0; i < 16; ++i) blk_b[EV4_ROW(l) + i] = yv[i];
-    blk_a[EV4_HEAD(l)] = yh;
-  };
-
-  double held[8]; /* terms 130..256 (mir[]) of the previous round (compute waves) */
-  /* Second part of a round (phases 1-3): DFT inputs out of the ring, first radix-16 pass, the transposes through the
-   * window's own block; a compute wave leaves the second pass's inputs in re / im.  The summing wave (BG) has a
-   * pass of its own between this part and the next: it parks the transposed re in the window's block and the
-   * transposed im in its own hand-over row (free since the pass that has just ended; [16][16], read back with 8-way
-   * conflicts once every W7 steps) instead of keeping 64 registers live across the pass. */
-  auto stage_dft1 = [&](int s, double (&re)[16], double (&im)[16], auto bg) __attribute__((always_inline)) {
-    constexpr bool BG = decltype(bg)::value;
-    const int xa = base5 + g, xb = xa + 1;
-    const int pa = xa >= 5 ? xa - 5 : xa, pb = xb >= 5 ? xb - 5 : xb;
-    double *blk_a = buf + pa * EV4_BLK, *blk_b = buf + pb * EV4_BLK;
-    ev_wave_sync();
-    /* DFT input of window g: lane l holds y[32*m1 + 2*l], y[32*m1 + 2*l + 1] */
-    {
-      const int off = EV4_ROW(l >> 3) + EV4_UNIT(l & 7); /* unit l & 7 of row 2 m1' or 2 m1' + 1 of the block */
-      const double *ia = blk_a + off, *ib = blk_b + off;
-      const double *i0 = l < 8 ? blk_a + EV4_HEAD(2 * l) : ia;
-      re[0] = i0[0];
-      im[0] = i0[1];
-#pragma unroll
-      for (int m1 = 1; m1 < 8; ++m1) { re[m1] = ia[EV4_ROW(2 * m1)]; im[m1] = ia[EV4_ROW(2 * m1) + 1]; }
-#pragma unroll
-      for (int m1 = 8; m1 < 16; ++m1) { re[m1] = ib[EV4_ROW(2 * (m1 - 8))]; im[m1] = ib[EV4_ROW(2 * (m1 - 8)) + 1]; }
-    }
-    ev_wave_sync(); /* window data is in registers; block g's place becomes exchange space */
-    if (!BG) { stamp(s, 2); phase(2); }
-    bl_fft16(re, im);
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) {
-      const c2d w = k1 < EV4_W1_REGS ? w1r[k1 < EV4_W1_REGS ? k1 : 0] : tw256x[(k1 - 13) * 16 + l];
-      bl_cmul(re[bl_pos16(k1)], im[bl_pos16(k1)], w.re, w.im);
-    }
-    if (!BG) { stamp(s, 3); phase(3); }
-    double *xg = blk_a; /* [16][18] doubles, re then im */
-    const double2 *xrow = reinterpret_cast<const double2 *>(xg + l * 18);
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = re[bl_pos16(k1)];
-    ev_wave_sync();
-    if (BG) {
-      double *sc = terms + (4 * wave + g) * EV_TROW;
-#pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) sc[k1 * 16 + l] = im[bl_pos16(k1)];
-      ev_wave_sync();
-      return;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; re[2 * q] = v.x; re[2 * q + 1] = v.y; }
-    ev_wave_sync();
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 18 + l] = im[bl_pos16(k1)];
-    ev_wave_sync();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
-    ev_wave_sync();
-  };
-  /* Third part (phases 4-5): second pass, power terms into this unit's four hand-over rows.  A compute wave waits
-   * for the rows, writes the second halves it kept from the round before and keeps this round's; the summing wave
-   * (BG) owns its rows and writes all 257 terms. */
-  auto stage_dft2 = [&](int s, double (&re)[16], double (&im)[16], auto bg) __attribute__((always_inline)) {
-    constexpr bool BG = decltype(bg)::value;
-    double *tg = terms + (4 * wave + g) * EV_TROW;
-    if (BG) { /* the second pass's inputs from where stage_dft1 parked them */
-      const int xa = base5 + g;
-      const double2 *xrow = reinterpret_cast<const double2 *>(buf + (xa >= 5 ? xa - 5 : xa) * EV4_BLK + l * 18);
-      const double2 *srow = reinterpret_cast<const double2 *>(tg + l * 16);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { const double2 v = xrow[q]; re[2 * q] = v.x; re[2 * q + 1] = v.y; }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { const double2 v = srow[q]; im[2 * q] = v.x; im[2 * q + 1] = v.y; }
-      ev_wave_sync();
-    }
-    if (!BG) {
-      stamp(s, 4);
-      phase(4);
-      /* the rows are free once the summing wave has taken tile seq - 1 out of them (placement of the wait, the
-       * sleep-free poll: k_env_windows3) */
-      stamp(s, 5);
-      phase(5);
-      while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) {}
-      ev_lds_acquire();
-      stamp(s, 6);
-#pragma unroll
-      for (int k0 = 0; k0 < 8; ++k0)
-        if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0]; /* terms 130..256 of the round before */
-    }
-    bl_fft16(re, im);
-    /* partner of pair k = k1 + 16 k0: Z[256 - k] = register 15 - k0 of lane (16 - k1) mod 16: row mirror + shift by
-     * one, lane 0 keeps `old` = its own register 16 - k0 (k_env_windows3) */
-    double mir7 = 0.0;
-#pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) {
-      const double sr = re[bl_pos16(15 - k0)], si = im[bl_pos16(15 - k0)];
-      const double zr = k0 ? re[bl_pos16(16 - k0)] : re[bl_pos16(0)];
-      const double zi = k0 ? im[bl_pos16(16 - k0)] : im[bl_pos16(0)];
-      const double pr = bl_dpp_f64_old<0x111>(zr, bl_dpp_f64<0x140>(sr));
-      const double pi = bl_dpp_f64_old<0x111>(zi, bl_dpp_f64<0x140>(si));
-      double own, mirv;
-      bl_fft512_power1<double, false>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, tw512[l + 16 * k0], own, mirv);
-      tg[l + 16 * k0] = own; /* terms 0..127 of this round */
-      if (BG) tg[256 - l - 16 * k0] = mirv; /* terms 129..256: lane 15 of k0 = 7 writes term 129 */
-      else {
-        held[k0] = mirv;
-        if (k0 == 7) mir7 = mirv;
-      }
-    }
-    /* |X_128|^2 = |Z_128|^2 has no 1/4 of its own: give back the one the halved input took */
-    const double mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
-    const double mid = 4.0 * __builtin_fma(mr, mr, mi * mi);
-    if (l == 0) tg[128] = mid;
-    if (!BG && l == 15) tg[129] = mir7; /* term 129 belongs to the first half */
-    ev_wave_sync();
-    if (!BG) {
-      if (ln == 0) flags[wave] = seq; /* no wait for the stores above: the LDS executes one wave's instructions in order */
-      stamp(s, 7);
-    }
-    base5 = base5 == 0 ? 4 : base5 - 1; /* (4 (rho + 1)) mod 5 */
-  };
-
-  if (wave == EV_CWAVES) {
-    /* ---- summing wave ---- */
-    __builtin_amdgcn_s_setprio(3);
-    if (W7) run_prologue();
-    const int n_steps = max(steps + 1, W7 ? W7 * (n7 - 1) + 5 : 0);
-    /* Step st (1-based).  Rows 0..27: every compute wave has published min(st, steps + 1); lane i adds terms 0..129
-     * of round st of row i's wave from 0 and keeps the partial sum, lane 32 + i takes the partial sum lane i made in
-     * step st - 1 and continues round st - 1 over terms 130..256 (127 terms and three zeros), then stores the energy.
-     * Rows 28..31 are this wave's own: round j of its run (0-based) is filtered after the pass of step W7 j + 1,
-     * transformed after the passes of steps W7 j + 2 and W7 j + 3, its first halves are added in step W7 j + 4 and its
-     * second halves in step W7 j + 5 — before the power terms of round j + 1 (after the pass of step W7 j + W7 + 3)
-     * overwrite the rows. */
-    const int rowi = ln & 31;
-    const bool own = ln < 32;
-    const int c2 = rowi >> 2;
-    const int q0 = run_begin(c2), q1 = run_begin(c2 + 1);
-    const double2 *row = reinterpret_cast<const double2 *>(terms + rowi * EV_TROW);
-    const double2 *zero2 = reinterpret_cast<const double2 *>(smem + EV4_ZERO_OFF);
-    const double2 *tp = own ? row : row + 65;
-    const double2 *tail = own ? row + 64 : zero2;
-    float psum = 0.f;
-    for (int st = 1; st <= n_steps; ++st) {
-      stamp(st - 1, 0);
-      const int want = min(st, steps + 1);
-      for (;;) {
-        const int f = ln < EV_CWAVES ? flags[ln] : want;
-        if (__all(f >= want)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      ev_lds_acquire();
-      stamp(st - 1, 1);
-      /* the round (1-based, within its unit's run) this lane works on; 0: none */
-      int rr;
-      if (c2 < EV_CWAVES) rr = own ? st : st - 1;
-      else {
-        const int t = st - (own ? 4 : 5);
-        rr = (W7 && t >= 0 && t % WCMP == 0) ? t / WCMP + 1 : 0;
-      }
-      const int rho = q0 + rr - 1, w = 4 * rho + (ln & 3);
-      const bool live = rr >= 1 && rho < q1 && w < sg.n_windows;
-      const float carried = __shfl(psum, ln & 31);
-      float sum = own ? 0.f : carried;
-      if (live) {
-        double2 ta[8], tb2[8];
-#define EV_LOAD8(T, B) _Pragma("unroll") for (int k = 0; k < 8; ++k) T[k] = tp[8 * (B) + k];
-#define EV_SUM8(T)                                                                                      \
-  _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                       \
-    sum = (float)((double)sum + T[k].x);                                                                \
-    sum = (float)((double)sum + T[k].y);                                                                \
-  }
-#define EV_SB __builtin_amdgcn_sched_barrier(0);
-        EV_LOAD8(ta, 0) EV_LOAD8(tb2, 1) EV_SB
-        EV_SUM8(ta) EV_SB EV_LOAD8(ta, 2) EV_SB
-        EV_SUM8(tb2) EV_SB EV_LOAD8(tb2, 3) EV_SB
-        EV_SUM8(ta) EV_SB EV_LOAD8(ta, 4) EV_SB
-        EV_SUM8(tb2) EV_SB EV_LOAD8(tb2, 5) EV_SB
-        EV_SUM8(ta) EV_SB EV_LOAD8(ta, 6) EV_SB
-        EV_SUM8(tb2) EV_SB EV_LOAD8(tb2, 7)
-        const double2 tl = tail[0];
-        EV_SB
-        EV_SUM8(ta) EV_SB
-        EV_SUM8(tb2)
-        sum = (float)((double)sum + tl.x);
-        sum = (float)((double)sum + tl.y);
-#undef EV_LOAD8
-#undef EV_SUM8
-#undef EV_SB
-      }
-      /* the rows are read: hand them back before the energies are stored */
-      ev_lds_release();
-      if (ln == 0) flags[8] = st;
-      psum = sum;
-      if (live && !own) {
-        energies[sg.env_off + w] = sum;
-        lc[sg.env_off + w] = bl_tail_compress((double)sum, tb.log101);
-      }
-      stamp(st - 1, 2);
-      if (W7) {
-        /* this wave's own round, a third of it per step */
-        const int j = (st - 1) / WCMP, part = (st - 1) % WCMP;
-        if (j < n7 && part < 3) {
-          const int pr7 = (PRIO >> 24) & 3;
-          if (pr7 == 0) __builtin_amdgcn_s_setprio(0);
-          else if (pr7 == 1) __builtin_amdgcn_s_setprio(1);
-          else if (pr7 == 2) __builtin_amdgcn_s_setprio(2);
-          if (part == 0) stage_fir(0, r0 + j, std::true_type{});
-          else if (part == 1) { double re[16], im[16]; stage_dft1(0, re, im, std::true_type{}); }
-          else { double re[16], im[16]; stage_dft2(0, re, im, std::true_type{}); }
-          __builtin_amdgcn_s_setprio(3);
-        }
-        stamp(st - 1, 3);
-      }
-    }
-    return;
-  }
-
-  /* ---- compute waves ---- */
-  run_prologue();
-#pragma unroll
-  for (int k0 = 0; k0 < 8; ++k0) held[k0] = 0.0;
-  /* a publication that carries nothing but the second halves of the round before */
-  auto publish_held_only = [&]() {
-    while (__builtin_amdgcn_readfirstlane(flags[8]) < seq - 1) __builtin_amdgcn_s_sleep(1);
-    ev_lds_acquire();
-    double *tg = terms + (4 * wave + g) * EV_TROW;
-#pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0)
-      if (k0 < 7 || l != 15) tg[256 - l - 16 * k0] = held[k0];
-    ev_wave_sync(); /* no wait: see the publication at the end of a round */
-  };
-  for (int s = 0; s < steps; ++s) {
-    ++seq;
-    const int rho = r0 + s;
-    if (rho >= r1) { /* this wave's run is one round shorter than its neighbours': nothing to hand over */
-      publish_held_only();
-      if (ln == 0) flags[wave] = seq;
-      continue;
-    }
-    stage_fir(s, rho, std::false_type{});
-    double re[16], im[16];
-    stage_dft1(s, re, im, std::false_type{});
-    stage_dft2(s, re, im, std::false_type{});
   }
   ++seq; /* the second halves of the last round: one more publication, nothing else in it */
   publish_held_only();
@@ -2260,25 +1791,18 @@ bl_tables blk_tables_bind(const void *d_mem) {
 }
 
 int blk_configure_device(void) {
-  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows4<0, BL_ENV_PRIO, false, BL_ENV_W7>),
-                         reinterpret_cast<const void *>(k_env_windows4<1, BL_ENV_PRIO, false, BL_ENV_W7>),
-                         reinterpret_cast<const void *>(k_env_windows4<2, BL_ENV_PRIO, false, BL_ENV_W7>)})
-    BL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, EV4_LDS_BYTES));
-#ifdef BL_AMD_MEASURE
-  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_PRIO & 0xFFFFFF, false>),
-                         reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_PRIO & 0xFFFFFF, true>)})
+  for (const void *fn : {reinterpret_cast<const void *>(k_env_windows3<0, BL_ENV_PRIO, false>),
+                         reinterpret_cast<const void *>(k_env_windows3<1, BL_ENV_PRIO, false>),
+                         reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_PRIO, false>)})
     BL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows4<2, BL_ENV_PRIO, true, BL_ENV_W7>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV4_LDS_BYTES));
+#ifdef BL_AMD_MEASURE
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, BL_ENV_PRIO, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
 #define X(T)                                                                                              \
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows4<2, T, false, 3>),        \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV4_LDS_BYTES));           \
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows4<2, T, true, 3>),         \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV4_LDS_BYTES));           \
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows4<2, T, false, 4>),        \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV4_LDS_BYTES));           \
-  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows4<2, T, false, 0>),        \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV4_LDS_BYTES));
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, T, false>),           \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));           \
+  BL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_windows3<2, T, true>),            \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, EV3_LDS_BYTES));
   EV_PRIO_TABS(X)
 #undef X
 #endif
@@ -2309,10 +1833,8 @@ struct Mark {
 static long long *g_env_probe = nullptr;
 #ifdef BL_AMD_MEASURE
 
-/* measurement builds only: pick a priority table of EV_PRIO_TABS at run time (-1: the compiled default; bits 0..27 the
- * table, bit 28 the PROBE instantiation, bits 29..30 the kernel: 0 k_env_windows4 with the summing wave's own rounds,
- * 1 k_env_windows3 (round 4, shipped table only), 2 k_env_windows4 with a pure summing wave, 3 with W7 = 4) and give the stamps a
- * device buffer of 8 x EV_PROBE_ROUNDS x EV_PROBE_SLOTS int64 */
+/* measurement builds only: pick a priority table of EV_PRIO_TABS at run time (-1: the compiled default; bits 24..:
+ * the PROBE instantiation) and give the stamps a device buffer of 8 x EV_PROBE_ROUNDS x EV_PROBE_SLOTS int64 */
 static int g_env_variant = -1;
 extern "C" __attribute__((visibility("default"))) int bl_amd_measure_env(int variant, void *d_probe) {
   g_env_variant = variant;
@@ -2423,31 +1945,24 @@ int blk_analyze(const blk_analyze_args &a) {
       Mark m(a.mark, a.mark_user, PK_ENV, stream);
       const int gx2 = grid_x_for(std::max(1, (2 * (maxn / 512)) / (4 * 4 * EV_CWAVES)), count, 2, a.n_cu);
       const dim3 grid(gx2, count), block(64 * (EV_CWAVES + 1));
-#define EV_LAUNCH(M, T, P, W)                                                                        \
-  hipLaunchKernelGGL((k_env_windows4<M, T, P, W>), grid, block, EV4_LDS_BYTES, stream, a.pcm, a.songs + first, \
+#define EV_LAUNCH(M, T, P)                                                                           \
+  hipLaunchKernelGGL((k_env_windows3<M, T, P>), grid, block, EV3_LDS_BYTES, stream, a.pcm, a.songs + first, \
                      a.stats + first, a.tb, a.energies, a.lc, g_env_probe)
 #ifdef BL_AMD_MEASURE
-      /* bl_amd_measure_env(): A/B of kernels and priority tables (FIR mode 2 only), with or without the phase stamps */
-      const int tab = g_env_variant & 0xFFFFFFF, kern = (g_env_variant >> 29) & 3;
-      const bool stamps = g_env_variant >= 0 && ((g_env_variant >> 28) & 1) != 0;
-      if (fir_mode == 2 && g_env_variant >= 0 && kern == 1) {
-        if (stamps)
-          hipLaunchKernelGGL((k_env_windows3<2, BL_ENV_PRIO & 0xFFFFFF, true>), grid, block, EV3_LDS_BYTES, stream, a.pcm,
-                             a.songs + first, a.stats + first, a.tb, a.energies, a.lc, g_env_probe);
-        else
-          hipLaunchKernelGGL((k_env_windows3<2, BL_ENV_PRIO & 0xFFFFFF, false>), grid, block, EV3_LDS_BYTES, stream, a.pcm,
-                             a.songs + first, a.stats + first, a.tb, a.energies, a.lc, g_env_probe);
-      } else if (fir_mode == 2 && g_env_variant >= 0 && (tab != BL_ENV_PRIO || stamps || kern == 2)) {
-        if (tab == BL_ENV_PRIO && kern == 0) EV_LAUNCH(2, BL_ENV_PRIO, true, BL_ENV_W7);
-#define X(T) else if (tab == (T)) { if (kern == 2) EV_LAUNCH(2, T, false, 0); else if (kern == 3) EV_LAUNCH(2, T, false, 4); else if (stamps) EV_LAUNCH(2, T, true, 3); else EV_LAUNCH(2, T, false, 3); }
+      /* bl_amd_measure_env(): A/B of the priority tables (FIR mode 2 only), with or without the phase stamps */
+      const int tab = g_env_variant & 0xFFFFFF;
+      const bool stamps = g_env_variant >= 0 && (g_env_variant >> 24) != 0;
+      if (fir_mode == 2 && g_env_variant >= 0 && (tab != BL_ENV_PRIO || stamps)) {
+        if (tab == BL_ENV_PRIO) EV_LAUNCH(2, BL_ENV_PRIO, true);
+#define X(T) else if (tab == (T)) { if (stamps) EV_LAUNCH(2, T, true); else EV_LAUNCH(2, T, false); }
         EV_PRIO_TABS(X)
 #undef X
         else return BL_UNEXPECTED;
       } else
 #endif
-      if (fir_mode == 2) EV_LAUNCH(2, BL_ENV_PRIO, false, BL_ENV_W7);
-      else if (fir_mode == 1) EV_LAUNCH(1, BL_ENV_PRIO, false, BL_ENV_W7);
-      else EV_LAUNCH(0, BL_ENV_PRIO, false, BL_ENV_W7);
+      if (fir_mode == 2) EV_LAUNCH(2, BL_ENV_PRIO, false);
+      else if (fir_mode == 1) EV_LAUNCH(1, BL_ENV_PRIO, false);
+      else EV_LAUNCH(0, BL_ENV_PRIO, false);
       return BL_OK;
 #undef EV_LAUNCH
     };

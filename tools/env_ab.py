@@ -1,13 +1,11 @@
 #!/usr/bin/env python3
-"""A/B of the envelope window kernels and their phase-priority tables (measurement build, bl_amd_measure_env): the
-same resident corpus analysed with every variant, results compared field by field with the shipped kernel's, the
-kernel timed with HIP events, and — for --probe variants — the s_memtime stamps of workgroup (0, 0) summarised per
-wave: where a compute wave's round goes (arithmetic phases, exchange phases, the wait in front of the hand-over).
-A variant is [kernel:]table.  table: seven hex digits, one priority (0..3) per phase of a compute wave's round, phase 0
-in the lowest digit, digit 6 the priority of the summing wave's own rounds; the measurement build instantiates the
-ones of EV_PRIO_TABS (bl_kernels.hip).  kernel: 0 k_env_windows4 (default), 1 k_env_windows3 (round 4; its shipped
-table only), 2 k_env_windows4 with a pure summing wave.  Prints one JSON object.
-usage: python tools/env_ab.py [--songs 1024] [--seconds 180] [--tabs 1:0222011,2:0222011,1222011] [--probe 0222011] [--reps 3]"""
+"""A/B of the phase-priority tables of k_env_windows3 (measurement build, bl_amd_measure_env): the same resident
+corpus analysed with every table, results compared field by field with the shipped table's, the kernel timed with
+HIP events, and — for --probe tables — the s_memtime stamps of workgroup (0, 0) summarised per wave: where a
+compute wave's round goes (arithmetic phases, exchange phases, the wait in front of the hand-over).
+A table is six hex digits, one priority (0..3) per phase, phase 0 in the lowest digit; the measurement build
+instantiates the ones of EV_PRIO_TABS (bl_kernels.hip) beside the shipped 222011.  Prints one JSON object.
+usage: python tools/env_ab.py [--songs 1024] [--seconds 180] [--tabs 000000,111111,322110] [--probe 222011] [--reps 3]"""
 import argparse
 import ctypes as C
 import json
@@ -27,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--songs", type=int, default=1024)
     ap.add_argument("--seconds", type=int, default=180)
-    ap.add_argument("--tabs", default="1:0222011,2:0222011,1222011,2222011")
+    ap.add_argument("--tabs", default="000000,111111,322110,321000,222110,222111,232011,222112")
     ap.add_argument("--probe", default="")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=3)
@@ -47,11 +45,7 @@ def main():
 
     def run(tab, with_probe=False):
         probe.zero_()
-        if tab is None:
-            var = -1
-        else:
-            kern, _, t = tab.rpartition(":")
-            var = int(t, 16) | ((1 << 28) if with_probe else 0) | (int(kern or 0) << 29)
+        var = -1 if tab is None else (int(tab, 16) | ((1 << 24) if with_probe else 0))
         assert lib.bl_amd_measure_env(var, C.c_void_p(probe.data_ptr()) if with_probe else None) == 0
         corpus.analyze()
         got = corpus.fetch()
@@ -104,15 +98,11 @@ def main():
             rep["waves"][str(w)] = dict({f"{SLOTS[i]}->{SLOTS[i + 1]}": round(float(d[i])) for i in range(7)},
                                         round_period=round(float(period)),
                                         start_offset_vs_wave0=round(float((t[:, 0] - st[0, 4:PROBE_ROUNDS, 0]).mean())))
-        t = st[7, 4:PROBE_ROUNDS, :4].astype(np.float64)
+        t = st[7, 4:PROBE_ROUNDS, :3].astype(np.float64)
         if t[:, 0].all():
             rep["summing_wave"] = {"wait_for_tile": round(float((t[:, 1] - t[:, 0]).mean())),
                                    "pass": round(float((t[:, 2] - t[:, 1]).mean())),
                                    "period": round(float(np.diff(t[:, 0]).mean()))}
-            if t[:, 3].all():  # k_env_windows4: the summing wave's own half rounds (FIR in even rows, DFT in odd)
-                own = t[:, 3] - t[:, 2]
-                rep["summing_wave"]["own_fir_half"] = round(float(own[0::2].mean()))
-                rep["summing_wave"]["own_dft_half"] = round(float(own[1::2].mean()))
         out["tables"][f"probe:{tab}"] = rep
     lib.bl_amd_measure_env(-1, None)
     print(json.dumps(out, indent=1))
