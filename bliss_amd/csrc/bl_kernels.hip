@@ -1132,20 +1132,28 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
 
   /* lane ln owns outputs 16 ln .. 16 ln + 15 of the round's 1 024 new samples and loads the 32
    * samples they read (four 16-byte loads), plus the sample that starts its zero-state output;
-   * fetched one round ahead.  The loads are unconditional and the addresses clamped into the song:
-   * what lies beyond its last window (or belongs to a round this wave does not run) only reaches
-   * windows that are never summed, so any sample will do there — no select, which would also put
-   * copies of these loop-carried registers at the loop latch. */
+   * fetched one round ahead.  Buffer loads: the song is the buffer, the lane's byte offset one register
+   * that moves on by 2 048 per round, and what lies beyond the song's last window reads as zero by the
+   * hardware's range check — it only reaches windows that are never summed, so any sample will do there.
+   * Two VALU instructions per round instead of the 21 that clamped 64-bit addresses took (round 5). */
   uint4 pre[4];
   short preh;
-  const int last8 = max(n_used - 8, 0);
-  auto fetch = [&](int rho_) {
-    const int base = 1024 * rho_ + 240 + 16 * ln; /* first input = first output - 16 */
+  const __amdgpu_buffer_rsrc_t prs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t *>(p), 0, (int)(2u * (unsigned)n_used), 0x00020000);
+  unsigned voff = 2u * (unsigned)(1024 * r0 + 240 + 16 * ln);  /* first input = first output - 16 */
+  unsigned voffh = 2u * (unsigned)(1024 * r0 + 256 * g + l);
+  typedef unsigned ev_v4u __attribute__((__vector_size__(16)));
+  auto fetch = [&]() {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pre[u] = *reinterpret_cast<const uint4 *>(p + min(base + 8 * u, last8));
-    preh = p[min(1024 * rho_ + 256 * g + l, n_used - 1)];
+    for (int u = 0; u < 4; ++u) {
+      const ev_v4u v = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)(voff + 16u * u), 0, 0);
+      pre[u] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    preh = (short)__builtin_amdgcn_raw_buffer_load_b16(prs, (int)voffh, 0, 0);
+    voff += 2048u;
+    voffh += 2048u;
   };
-  fetch(r0);
+  fetch();
   double held[8]; /* terms 130..256 (mir[]) of the previous round */
 #pragma unroll
   for (int k0 = 0; k0 < 8; ++k0) held[k0] = 0.0;
@@ -1185,7 +1193,7 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
       }
       const int kh = (int)preh - mean;   /* this round's head sample: fetch() below overwrites preh */
       const double xh = nrm(kh);
-      fetch(rho + 1); /* next round's samples */
+      fetch(); /* next round's samples */
       /* 2. FIR (ref :123-138): outputs 16 ln .. 16 ln + 15 of the round's new samples */
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
