@@ -81,6 +81,7 @@ DEFINE_CFFT(cfft256_f64, double, g_cw, g_sw)
 /* f32, in place, FFmpeg RDFT packed output:
  * x[0]=Re X0, x[1]=Re X256, x[2k]=Re Xk, x[2k+1]=Im Xk (k=1..255). */
 void orc_rdft512_f32(float *x) {
+  if (orc_fft_variant() != 0) { orc_alt_rdft512_f32(orc_fft_variant(), x); return; } /* cross-checks: orc_fft_alt.c */
   float zr[HALF], zi[HALF];
   init_tables();
   for (int m = 0; m < HALF; ++m) { zr[m] = x[2 * m]; zi[m] = x[2 * m + 1]; }
@@ -99,6 +100,7 @@ void orc_rdft512_f32(float *x) {
 
 /* f64, out of place: re[k], im[k] for k = 0..256 (FFTW r2c layout). */
 void orc_r2c512_f64(const double *in, double *re, double *im) {
+  if (orc_fft_variant() != 0) { orc_alt_r2c512_f64(orc_fft_variant(), in, re, im); return; }
   double zr[HALF], zi[HALF];
   init_tables();
   for (int m = 0; m < HALF; ++m) { zr[m] = in[2 * m]; zi[m] = in[2 * m + 1]; }

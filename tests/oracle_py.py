@@ -28,7 +28,7 @@ FIELDS = [f[0] for f in OrcResult._fields_]
 def build_oracle():
     if not os.path.exists(LIB) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB)
-            for f in ("bliss_oracle.c", "orc_fft.c", "orc_synth.c", "bliss_oracle.h")):
+            for f in ("bliss_oracle.c", "orc_fft.c", "orc_fft_alt.c", "orc_synth.c", "bliss_oracle.h")):
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
     return LIB
 
@@ -62,10 +62,20 @@ class Oracle:
         L.orc_cosine_matrix.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
         L.orc_synth_fill.restype = None
         L.orc_synth_fill.argtypes = [i16p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_set_fft_variant.restype = None
+        L.orc_set_fft_variant.argtypes = [C.c_int]
 
     @staticmethod
     def _p(a):
         return a.ctypes.data_as(C.POINTER(C.c_int16))
+
+    def set_fft_variant(self, v):
+        """0 packed radix-2 (default), 1 recursive radix-4 on the unpacked input, 2 the defining sum (orc_fft_alt.c)"""
+        self.lib.orc_set_fft_variant(v)
+
+    def frequency(self, pcm, channels):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        return float(self.lib.orc_frequency(self._p(pcm), pcm.size, channels, None))
 
     def synth(self, seed, rate, channels, n):
         out = np.empty(n, dtype=np.int16)
