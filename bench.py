@@ -23,11 +23,17 @@ sharding and the all-gather on stand-in vectors without a GPU: the CPU test of t
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import subprocess
 import sys
+import threading
 import time
+
+# dmabuf IPC: RCCL (and any CUDA-tensor sharing across processes) needs it on this driver; it has to be in the
+# environment before the HIP runtime starts, whichever launcher started this rank
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -38,6 +44,76 @@ SAMPLE_RATE = 44100
 HBM_PEAK_GBS = 8000.0                   # spec, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6290.0             # measured float4 copy, same guide
 FP64_VALU_PEAK_TFLOPS = 78.6            # spec (FMA = 2 flop); the faithful path's real ceiling
+
+
+class DeviceState(threading.Thread):
+    """Shader clock, socket power and temperature of one GPU while something runs on it: a thread that reads the
+    amdgpu hwmon files of the device with PCI address `bdf` every `period` seconds.  The envelope window kernel does not
+    run at the 2.4 GHz the part is specified with (f64 vector load: ~2.2 GHz at ~1.15 kW on the boxes measured), and
+    boxes differ by a few per cent; this is what makes a slow lease distinguishable from a regression."""
+
+    FILES = ("freq1_input", "power1_average", "power1_input", "temp2_input", "temp1_input", "power1_cap")
+
+    def __init__(self, bdf, period=0.02):
+        super().__init__(daemon=True)
+        self.period, self.rows, self.stop_flag, self.files = period, [], False, {}
+        self.bdf = bdf
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            dev = os.path.join(card, "device")
+            try:
+                if os.path.basename(os.path.realpath(dev)).lower() != (bdf or "").lower():
+                    continue
+            except OSError:
+                continue
+            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                for f in self.FILES:
+                    if os.path.exists(os.path.join(hw, f)):
+                        self.files[f] = os.path.join(hw, f)
+            break
+
+    @staticmethod
+    def pci_address(ordinal):
+        try:
+            buf = C.create_string_buffer(64)
+            if C.CDLL("libamdhip64.so").hipDeviceGetPCIBusId(buf, 64, int(ordinal)) == 0:
+                return buf.value.decode()
+        except OSError:
+            pass
+        return None
+
+    @staticmethod
+    def _rd(path, scale):
+        try:
+            with open(path) as f:
+                return float(f.read().strip()) / scale
+        except (OSError, ValueError):
+            return None
+
+    def run(self):
+        f = self.files
+        while not self.stop_flag and "freq1_input" in f:
+            t = time.perf_counter()
+            self.rows.append((t, self._rd(f["freq1_input"], 1e6),
+                              self._rd(f.get("power1_average") or f.get("power1_input", ""), 1e6),
+                              self._rd(f.get("temp2_input") or f.get("temp1_input", ""), 1e3)))
+            dt = self.period - (time.perf_counter() - t)
+            if dt > 0:
+                time.sleep(dt)
+
+    def summary(self, t0, t1):
+        import numpy as np
+        sel = [r for r in self.rows if t0 <= r[0] <= t1]
+        out = {"pci": self.bdf, "samples": len(sel), "period_s": self.period,
+               "source": "amdgpu hwmon (freq1_input / power1_* / temp*_input) of this rank's device, sampled over the "
+                         "timed region" if self.files else "no amdgpu hwmon files found for this device"}
+        for j, k in ((1, "sclk_mhz"), (2, "power_w"), (3, "temp_c")):
+            v = np.array([r[j] for r in sel if r[j] is not None], dtype=float)
+            if len(v):
+                out[k] = {"mean": round(float(v.mean()), 1), "min": round(float(v.min()), 1),
+                          "p50": round(float(np.median(v)), 1), "max": round(float(v.max()), 1)}
+        cap = self._rd(self.files["power1_cap"], 1e6) if "power1_cap" in self.files else None
+        out["power_cap_w"] = cap
+        return out
 
 
 def _cpu_limits():
@@ -169,7 +245,7 @@ def verify_songs(res, picks, seed_first, seconds):
             if not rel <= 1e-4:
                 bad.append(k)
         details.append({"song": int(i), "beat": int(g["beat"]), "max_rel_err": worst, "rel_err_by_field": by_field,
-                        "mismatch": bad})
+                        "value_by_field": {k: float(ref[k]) for k in by_field}, "mismatch": bad})
         ok = ok and not bad
     return ok, details
 
@@ -212,6 +288,85 @@ def _committed_profile(songs, song_samples):
     return out
 
 
+def _oracle_check(res, lengths, channels, durations, picks, seed_first):
+    """Untimed: songs `picks` of a batch re-synthesised on the host and analysed by the CPU oracle (orc_cli synthn, one
+    process per song); integers identical, f32 features <= 1e-4 relative."""
+    from tests.oracle_py import build_oracle
+    build_oracle()
+    cli = os.path.join(ROOT, "oracle", "orc_cli")
+    procs = [subprocess.Popen([cli, "synthn", str(seed_first + i), str(SAMPLE_RATE), str(channels[i]), str(lengths[i]),
+                               str(durations[i])], stdout=subprocess.PIPE, text=True) for i in picks]
+    ok, worst = True, 0.0
+    for i, p in zip(picks, procs):
+        o, _ = p.communicate()
+        ref = json.loads(o.strip().splitlines()[-1])
+        g = res[i]
+        ok = ok and all(int(g[k]) == int(ref[k]) for k in ("start", "end", "mean", "variance", "n_frames", "nb_frames",
+                                                            "n_windows", "beat", "calm_or_loud"))
+        for k in ("tempo", "amplitude", "frequency", "attack", "force"):
+            rel = abs(float(g[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-6)
+            worst = max(worst, rel)
+            ok = ok and rel <= 1e-4
+    return bool(ok), worst
+
+
+def other_configs(lib, dev, main_songs, steps=3):
+    """BASELINE configs[1] and configs[4] through the same library, timed by this process after the main run (its
+    resident batch has been freed): not `value`, which the contract quotes on configs[2] — the driver's clock on the
+    other two shapes.  configs[1]: 1 024 synthetic 30-s 44.1 kHz s16 stereo buffers.  configs[4]: songs of log-uniform
+    length in [10 s, 600 s] at 44.1 kHz, half mono / half stereo (the corpus of tools/mixed_bench.py; s32 sources are
+    narrowed to s16 before the analysis and analysed as s16: the parity tests cover that path, this times the analysis)."""
+    import numpy as np
+    import torch
+    import bliss_amd
+    out = {}
+
+    def run(name, lengths, channels, durations, seed0, what):
+        corpus = bliss_amd.DeviceCorpus(lengths, channels, durations, device=str(dev))
+        corpus.synth(seed_base=seed0, sample_rate=SAMPLE_RATE)
+        corpus.analyze()
+        torch.cuda.synchronize(dev)
+        lib.bl_amd_profile_reset()
+        lib.bl_amd_profile(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            corpus.analyze()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        lib.bl_amd_profile(0)
+        kern = {}
+        for k in ("freq_scan", "env_windows", "env_tail", "amp_finish"):
+            n = C.c_int(0)
+            ms = lib.bl_amd_profile_ms(k.encode(), C.byref(n))
+            kern[k] = ms / steps      # per batch (a mixed batch launches the window and tail kernels twice)
+        res = corpus.fetch()
+        n = len(lengths)
+        order = np.argsort(np.asarray(lengths))
+        picks = sorted(set(int(order[int(q * (n - 1))]) for q in (0.0, 0.3, 0.6, 0.85)))   # by length; not the longest: ~1 s of oracle each
+        ok, worst = _oracle_check(res, lengths, channels, durations, picks, seed0)
+        ok = ok and bool(np.all(res["status"] == 0))
+        gb = corpus.pcm_bytes / 1e9
+        out[name] = {"workload": what, "songs": n, "pcm_GB": gb, "ms_per_batch": 1e3 * dt, "songs_per_s": n / dt,
+                     "pcm_GB_per_s": gb / dt, "frac_hbm": gb / dt / HBM_PEAK_GBS, "kernels_ms_per_batch": kern,
+                     "steps": steps, "results_ok": ok, "verified_songs": len(picks), "worst_rel_err": worst}
+        del corpus
+        torch.cuda.empty_cache()
+
+    n1 = 1024 if main_songs >= 1024 else max(4, main_songs)
+    run("configs1", [SAMPLE_RATE * 2 * 30] * n1, [2] * n1, [30] * n1, 700000,
+        f"BASELINE configs[1]: {n1} synthetic 30-s 44.1 kHz s16 stereo buffers, one batch call")
+    n4 = min(8192, max(8, main_songs))
+    rng = np.random.default_rng(5)
+    secs = np.exp(rng.uniform(np.log(10.0), np.log(600.0), n4))
+    ch = rng.integers(1, 3, n4)
+    lengths = (np.floor(secs * SAMPLE_RATE).astype(np.int64) * ch).tolist()
+    durs = np.maximum(1, np.floor(secs)).astype(np.int64).tolist()
+    run("configs4_mixed", lengths, ch.tolist(), durs, 0,
+        f"BASELINE configs[4] shape: {n4} songs of log-uniform length in [10 s, 600 s] at 44.1 kHz, half mono / half "
+        "stereo, s16, one batch call (long songs first, own window launch: DESIGN.md section 4.2)")
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -234,8 +389,7 @@ def self_launch(args, argv):
             print(f"bench.py --gpus {args.gpus}: this box exposes {have} HIP device(s); the N-GPU run needs "
                   f"{args.gpus} (one rank per GPU).  Nothing was launched.", file=sys.stderr)
             return 2
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env = dict(os.environ)   # HSA_ENABLE_IPC_MODE_LEGACY=0 is in it (top of this file)
     env["MASTER_ADDR"] = "127.0.0.1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
@@ -317,6 +471,8 @@ def main():
                     help="skip the untimed extra pass in FIR mode 0 (profiling runs: one envelope launch per step)")
     ap.add_argument("--cpu-ladder", default="1,8,32,64,128,256",
                     help="concurrent oracle processes per rung of the CPU baseline (tests shorten it)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the untimed-for-value legs on BASELINE configs[1] and configs[4] (profiling runs)")
     ap.add_argument("--verify", type=int, default=32,
                     help="songs of the resident batch re-analysed by the CPU oracle after the timed region")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -433,6 +589,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    devstate = DeviceState(DeviceState.pci_address(local_rank))
+    devstate.start()
     lib.bl_amd_profile_reset()
     lib.bl_amd_profile(1)
     t0 = time.perf_counter()
@@ -441,6 +599,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.bl_amd_profile(0)
+    devstate.stop_flag = True
+    device_state = devstate.summary(t0, t0 + elapsed)
     my_elapsed = elapsed
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -458,10 +618,12 @@ def main():
 
     # every rank's own clock and its dominant kernel, so that a scaling loss can be put on a slow rank (a gather of
     # two doubles per rank) rather than on the collective
-    mine2 = torch.tensor([1e3 * my_elapsed / args.steps, kern["env_windows"]["ms_avg"] or 0.0], dtype=torch.float64, device=cdev)
+    mine2 = torch.tensor([1e3 * my_elapsed / args.steps, kern["env_windows"]["ms_avg"] or 0.0,
+                          (device_state.get("sclk_mhz") or {}).get("mean", 0.0), (device_state.get("power_w") or {}).get("mean", 0.0)],
+                         dtype=torch.float64, device=cdev)
     per_rank = mine2.unsqueeze(0)
     if dist.is_initialized():
-        per_rank = torch.empty((world, 2), dtype=torch.float64, device=cdev)
+        per_rank = torch.empty((world, 4), dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(per_rank, mine2.unsqueeze(0))
     per_rank = per_rank.cpu().numpy()
 
@@ -580,7 +742,33 @@ def main():
                                         "unit": "GB/s", "frac": launch_bytes / (1e-3 * kern["freq_scan"]["ms_avg"]) / 1e9
                                         / HBM_PEAK_GBS, "bound": "issue (DESIGN.md section 4.4)"}
                                        if kern.get("freq_scan", {}).get("ms_avg") else None)}
+            if fir_report.get("mode0_env_windows_ms"):
+                roof["frac_fir_mode0"] = launch_bytes / (1e-3 * fir_report["mode0_env_windows_ms"]) / 1e9 / HBM_PEAK_GBS
+                roof["frac_of_f64_floor_fir_mode0"] = (windows * F64_FLOOR_INSTR_PER_WINDOW[0] / (F64_ISSUE_TWAVEINSTR_S * 1e12)
+                                                       / (1e-3 * fir_report["mode0_env_windows_ms"]))
         whole_path_gbs = value / world * alg_bytes_song / 1e9
+        # the reference's operation order (FIR mode 0): the step with the mode-0 window kernel's time in place of the
+        # timed mode's — the strict-order throughput beside `value`
+        value_mode0 = ms_per_step_mode0 = None
+        if fir_active == 0:
+            value_mode0, ms_per_step_mode0 = value, ms_per_step
+        elif fir_report.get("mode0_env_windows_ms") and dom["ms_avg"]:
+            ms_per_step_mode0 = ms_per_step + fir_report["mode0_env_windows_ms"] - dom["ms_avg"]
+            value_mode0 = total_songs / (1e-3 * ms_per_step_mode0)
+        # the literal north_star bar, per field: |gpu - oracle| <= 1e-4 |oracle| with no absolute term
+        strict = {k: int(sum(1 for d in verify_details if not d["rel_err_by_field"][k] <= 1e-4))
+                  for k in ("tempo", "amplitude", "frequency", "attack", "force")}
+
+        # the driver's clock on the other two batch shapes of BASELINE.json (the resident batch is freed first)
+        others = None
+        if not args.no_other_configs:
+            try:
+                del corpus
+                del rows, all_vecs
+                torch.cuda.empty_cache()
+                others = other_configs(lib, dev, songs)
+            except Exception as e:   # a diagnostic leg must never sink the line
+                others = {"error": f"{type(e).__name__}: {e}"}
 
         # BASELINE config 4: standalone 10 000 x 10 000 bl_distance matrix on one GPU
         g = torch.Generator(device="cpu").manual_seed(4)
@@ -615,6 +803,7 @@ def main():
             "metric": "songs/sec bl_analyze (3-min 44.1kHz s16) + 10k x 10k distance-matrix sec",
             "value": value, "unit": "songs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "value_fir_mode0": value_mode0, "ms_per_step_fir_mode0": ms_per_step_mode0,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2] shape: {songs} synthetic {args.seconds}-s 44.1 kHz s16 "
                                    f"stereo songs resident per GPU ({songs * song_bytes / 1e9:.1f} GB PCM/GPU"
@@ -636,7 +825,8 @@ def main():
             "verification": {"against": "CPU oracle (oracle/orc_cli) on the re-synthesised songs, untimed; every rank "
                                         "checks its share of --verify (results_ok / verified_songs are reduced over the "
                                         "ranks, the list below is rank 0's)",
-                             "bar": "integers identical, f32 features <= 1e-4 relative",
+                             "bar": "integers identical, f32 features <= 1e-4 relative (no absolute term)",
+                             "n_failing_strict_1e-4_rel": strict,
                              "worst_rel_err_by_field": {k: max((d["rel_err_by_field"][k] for d in verify_details), default=None)
                                                         for k in ("tempo", "amplitude", "frequency", "attack", "force")},
                              "songs": verify_details},
@@ -653,6 +843,9 @@ def main():
                          "env_windows_ms": [float(x) for x in per_rank[:, 1]],
                          "what": "each rank's own wall clock over the timed steps (the line's ms_per_step is the max) "
                                  "and its k_env_windows3 HIP-event average"},
+            "device_state": dict(device_state, per_rank_sclk_mhz=[float(x) for x in per_rank[:, 2]],
+                                 per_rank_power_w=[float(x) for x in per_rank[:, 3]]),
+            "other_configs": others,
             "roofline": roof,
         }
         # the CPU baseline runs on rank 0 at every N (after the timed region and every reduction; the other

@@ -2,6 +2,7 @@
  * orc_cli.c — TEST INFRASTRUCTURE.  Command-line driver of the CPU oracle.
  *   orc_cli raw  <file.s16le> <channels> <duration>     analyse raw PCM
  *   orc_cli synth <seed> <rate> <channels> <seconds>     analyse a synthetic song
+ *   orc_cli synthn <seed> <rate> <channels> <n_samples> <duration>   the same, any length (n interleaved samples)
  *   orc_cli time <seed> <rate> <channels> <seconds> <count>   time `count` songs
  * Prints one JSON object per song.
  */
@@ -39,6 +40,17 @@ int main(int argc, char **argv) {
     fclose(f);
     orc_result r;
     orc_analyze_pcm(pcm, (int)(bytes / 2), atoi(argv[3]), strtoull(argv[4], 0, 10), &r);
+    print_result(&r);
+    free(pcm);
+    return 0;
+  }
+  if (argc >= 7 && !strcmp(argv[1], "synthn")) {
+    uint32_t seed = strtoul(argv[2], 0, 10), rate = strtoul(argv[3], 0, 10), ch = strtoul(argv[4], 0, 10);
+    uint32_t n = strtoul(argv[5], 0, 10);
+    int16_t *pcm = (int16_t *)malloc((size_t)n * 2 + 2);
+    orc_synth_fill(pcm, n, seed, rate, ch);
+    orc_result r;
+    orc_analyze_pcm(pcm, (int)n, (int)ch, strtoull(argv[6], 0, 10), &r);
     print_result(&r);
     free(pcm);
     return 0;

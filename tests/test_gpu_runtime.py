@@ -232,11 +232,12 @@ def test_invalid_host_descriptors_fail_before_staging(gpu_lib):
     assert gpu_lib.bl_amd_analyze_batch_host(ptrs, ns, ch, du, 2, out) == _lib.BL_UNEXPECTED   # negative length
 
 
-@pytest.mark.parametrize("devices,gather", [([0], "rccl"), ([0], "peer"), ([0, 0], "peer"), ([0, 0, 0], "peer")])
-def test_corpus_multi(gpu_lib, oracle, devices, gather):
-    """The C-ABI batch-of-songs mode.  RCCL (ncclCommInitAll + ncclAllGather) runs at world size
-    1; the peer gather also takes several ranks on one device, which exercises the sharding, the
-    per-rank contexts and threads, the exchange and the row-block matrix with W = 2, 3."""
+def _all_devices():
+    import torch
+    return list(range(torch.cuda.device_count()))
+
+
+def _check_corpus_multi(oracle, devices, gather):
     songs = _songs(oracle, 4500, 11)
     for equal in (False, True):
         use = songs if not equal else [(oracle.synth(4600 + i, 22050, 2, 22050 * 2 * 6), 2, 6) for i in range(7)]
@@ -252,12 +253,29 @@ def test_corpus_multi(gpu_lib, oracle, devices, gather):
     assert none is None
 
 
-@pytest.mark.parametrize("counts,gather", [((5,), "rccl"), ((4, 3), "peer"), ((3, 0, 4), "peer"), ((2, 3, 2), "peer")])
-def test_corpus_multi_device_resident(gpu_lib, oracle, counts, gather):
-    """bl_amd_analyze_corpus_multi_device: the corpus already resident, one arena per rank (here
-    all on device 0, separate contexts and host threads; an empty shard included).  Records and
-    matrix must equal the single-context path bit for bit, the row blocks left in HBM too."""
+@pytest.mark.parametrize("devices,gather", [([0], "rccl"), ([0], "peer"), ([0, 0], "peer"), ([0, 0, 0], "peer")])
+def test_corpus_multi(gpu_lib, oracle, devices, gather):
+    """The C-ABI batch-of-songs mode.  RCCL (ncclCommInitAll + ncclAllGather) runs at world size
+    1; the peer gather also takes several ranks on one device, which exercises the sharding, the
+    per-rank contexts and threads, the exchange and the row-block matrix with W = 2, 3."""
+    _check_corpus_multi(oracle, devices, gather)
+
+
+@pytest.mark.parametrize("gather", ["rccl", "peer"])
+def test_corpus_multi_on_every_device(gpu_lib, oracle, gather):
+    """The same on every HIP device the box has, one rank per device: ncclCommInitAll over N devices and an
+    ncclAllGather that crosses xGMI, or hipMemcpyPeerAsync between devices.  Skipped on a one-GPU box; on an N-GPU
+    box it runs without an edit."""
+    devices = _all_devices()
+    if len(devices) < 2:
+        pytest.skip("one HIP device on this box: W > 1 is covered on device 0 by test_corpus_multi")
+    _check_corpus_multi(oracle, devices, gather)
+    _check_corpus_multi(oracle, devices[::-1], gather)     # rank r need not sit on device r
+
+
+def _check_corpus_multi_device_resident(oracle, counts, gather, devices=None):
     import torch
+    devices = devices or [0] * len(counts)
     songs = _songs(oracle, 4700, sum(counts))
     pcms, chans, durs = [p for p, _, _ in songs], [c for _, c, _ in songs], [d for _, _, d in songs]
     whole = bliss_amd.DeviceCorpus([p.size for p in pcms], chans, durs)
@@ -268,10 +286,10 @@ def test_corpus_multi_device_resident(gpu_lib, oracle, counts, gather):
     fv = np.stack([single[k] for k in ("tempo", "amplitude", "frequency", "attack")], axis=1)
     want = bliss_amd.distance_matrix(fv)
     corpora, first = [], 0
-    for cnt in counts:
+    for cnt, d in zip(counts, devices):
         part = range(first, first + cnt)
         c = bliss_amd.DeviceCorpus([pcms[i].size for i in part] or [8], [chans[i] for i in part] or [1],
-                                   [durs[i] for i in part] or [1])
+                                   [durs[i] for i in part] or [1], device=f"cuda:{d}")
         if cnt == 0:
             c.n_songs = 0          # an empty shard: the arena exists, nothing to analyse
         for k, i in enumerate(part):
@@ -282,7 +300,8 @@ def test_corpus_multi_device_resident(gpu_lib, oracle, counts, gather):
         res, mat, rows = bliss_amd.analyze_corpus_multi_device(corpora, gather=gather, keep_rows=True)
         _same(single, res)
         assert np.array_equal(mat, want) and np.array_equal(mat, oracle.distance_matrix(fv))
-        torch.cuda.synchronize()
+        for d in set(devices):
+            torch.cuda.synchronize(d)
         assert np.array_equal(np.concatenate([r.cpu().numpy() for r in rows], axis=0), want)
     # the shard's own device records are the same records
     off = 0
@@ -293,6 +312,28 @@ def test_corpus_multi_device_resident(gpu_lib, oracle, counts, gather):
     res2, none, _ = bliss_amd.analyze_corpus_multi_device(corpora, gather=gather, matrix=False)
     _same(single, res2)
     assert none is None
+
+
+@pytest.mark.parametrize("counts,gather", [((5,), "rccl"), ((4, 3), "peer"), ((3, 0, 4), "peer"), ((2, 3, 2), "peer")])
+def test_corpus_multi_device_resident(gpu_lib, oracle, counts, gather):
+    """bl_amd_analyze_corpus_multi_device: the corpus already resident, one arena per rank (here
+    all on device 0, separate contexts and host threads; an empty shard included).  Records and
+    matrix must equal the single-context path bit for bit, the row blocks left in HBM too."""
+    _check_corpus_multi_device_resident(oracle, counts, gather)
+
+
+@pytest.mark.parametrize("gather", ["rccl", "peer"])
+def test_corpus_multi_device_resident_on_every_device(gpu_lib, oracle, gather):
+    """One resident shard per HIP device of the box (uneven counts, the last but one empty when there are more than
+    two): the vectors cross xGMI by RCCL or by peer copies, every device computes its own row block.  Skipped on a
+    one-GPU box."""
+    devices = _all_devices()
+    if len(devices) < 2:
+        pytest.skip("one HIP device on this box: W > 1 is covered on device 0 by test_corpus_multi_device_resident")
+    counts = [3 + (d % 3) for d in devices]
+    if len(devices) > 2:
+        counts[-2] = 0
+    _check_corpus_multi_device_resident(oracle, tuple(counts), gather, devices)
 
 
 def test_scalar_helpers_match_the_kernels(gpu_lib):

@@ -108,6 +108,13 @@ def test_bench_under_torchrun_runs_rccl_and_verifies(gpu_lib):
     assert line["n_gpus"] == 1 and line["results_ok"] is True and line["verified_songs"] == 4
     assert line["collective"]["backend"] == "nccl" and line["collective"]["all_gather_calls"] >= 2
     assert line["roofline"]["kernel"] and line["value"] > 0
+    # the strict-order figures and the literal north_star bar stand on the line itself
+    assert 0 < line["value_fir_mode0"] <= line["value"] * 1.05 and line["roofline"]["frac_fir_mode0"] > 0
+    assert set(line["verification"]["n_failing_strict_1e-4_rel"]) == {"tempo", "amplitude", "frequency", "attack", "force"}
+    assert line["device_state"]["samples"] >= 0 and "pci" in line["device_state"]
+    oc = line["other_configs"]
+    assert oc["configs1"]["results_ok"] is True and oc["configs4_mixed"]["results_ok"] is True
+    assert oc["configs1"]["songs_per_s"] > 0 and oc["configs4_mixed"]["verified_songs"] >= 3
 
 
 def test_bench_self_launch(gpu_lib):
@@ -131,6 +138,31 @@ def test_bench_self_launch(gpu_lib):
                             stderr=subprocess.PIPE, text=True, timeout=300)
         assert r2.returncode == 2 and r2.stdout.strip() == ""
         assert "1 HIP device(s)" in r2.stderr and "WORLD_SIZE" not in r2.stderr
+
+
+def test_bench_on_every_gpu_of_the_box(gpu_lib):
+    """`python bench.py --gpus <all>` on a box with more than one HIP device: N ranks under torch.distributed.run, an
+    RCCL group of N, the all-gather of the force vectors across xGMI, every rank's row block and its share of the
+    oracle check.  Skipped on a one-GPU box (there test_bench_two_ranks_rehearsal_on_one_gpu runs the N-rank code
+    over gloo); on the first multi-GPU lease it runs as it stands."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one HIP device on this box")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--songs-per-gpu", "64", "--seconds", "30", "--cpu-ladder", "1,8", "--verify", str(4 * n), "--no-other-configs"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n and line["results_ok"] is True and line["verified_songs"] == 4 * n
+    assert line["collective"]["backend"] == "nccl" and line["collective"]["all_gather_calls"] >= 3
+    assert line["config"]["parallelism"] == f"shard{n}" and f"{64 * n} songs total" in line["config"]["workload"]
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == n == len(pr["env_windows_ms"]) and min(pr["env_windows_ms"]) > 0
+    assert len(line["device_state"]["per_rank_sclk_mhz"]) == n
+    assert line["rehearsal"] is None and line["scaling"] == "weak" and line["value"] > 0
 
 
 def test_fir_modes_agree(gpu_lib, oracle):
