@@ -10,11 +10,13 @@
  * What depends on one vector only is computed once per vector (bl_cos_prep): n, s = sqrt((double)n) and
  * r = 1 / s, both correctly rounded.  Per pair the fast path evaluates
  *     q' = (double)dot * (ra * rb)
- * which differs from the reference's double quotient q = RN(dot / RN(sa * sb)) by at most 3.5 ulp of q
- * (0.5 ulp each for ra, rb, their product, the reference's sa * sb, and the two final roundings).  (float)q'
- * equals (float)q whenever no float rounding boundary — a double whose low 29 mantissa bits are 0x10000000 —
- * lies within that distance of q', so the fast result is taken only if the low 29 bits of q' are further than
- * BL_COS_GUARD ulp from 0x10000000 and q' is a normal number of a magnitude where a float has its full 24 bits;
+ * which differs from the reference's double quotient q = RN(dot / RN(sa * sb)) by less than 6 ulp of q: six
+ * roundings of relative size u = 2^-53 separate the two (ra, rb, ra * rb, dot * R, the reference's sa * sb, and
+ * its quotient), i.e. 6 u relative, which is between 3 and 6 ulp of q depending on where q sits in its binade
+ * (plus the case of q' and q on either side of a power of two, where the ulp halves: still below 12 of the smaller
+ * ulp).  (float)q' equals (float)q whenever no float rounding boundary — a double whose low 29 mantissa bits are
+ * 0x10000000 — lies within that distance of q', so the fast result is taken only if the low 29 bits of q' are further
+ * than BL_COS_GUARD = 16 ulp from 0x10000000 and q' is a normal number of a magnitude where a float has its full 24 bits;
  * everything else (one pair in ~10^7, zero or non-finite norms, zero dot products) takes the plain expression.
  * Not taken on trust: bl_amd_selftest_cos() sweeps random and boundary-seeking (dot, na, nb) triples on the
  * device against the plain expression and reports the largest |q' - q| it saw, in ulp.
@@ -24,7 +26,7 @@
 
 #include <hip/hip_runtime.h>
 
-#define BL_COS_GUARD 16 /* ulp of the double quotient; 3.5 are needed */
+#define BL_COS_GUARD 16 /* ulp of the double quotient; the provable distance is < 6 (12 across a binade edge) */
 
 struct bl_cos_vec { double s, r; float n; };
 

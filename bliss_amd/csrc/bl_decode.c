@@ -59,8 +59,6 @@ static int native_rate_allowed(void) {
   const char *e = getenv("BL_AMD_ALLOW_NATIVE_RATE"); /* not cached: getenv is cheap next to a decode */
   return e && *e && strcmp(e, "0") != 0;
 }
-/* read ONCE per decode (bl_audio_decode stores the answer in the sink): the setter may run while a
- * decode is in flight, and a sink filled as wide must not meet a branch that expects narrowed samples */
 
 /* a sample of `bps` significant bits as the s16 the analyzers read: left-justify in 32 bits,
  * arithmetic >> 16 */

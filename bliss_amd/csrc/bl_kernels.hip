@@ -79,7 +79,20 @@ __device__ __forceinline__ void bl_wave_sync() {
  * tests/test_gpu_parity.py::test_histogram_out_of_range_samples_are_dropped).  4 instructions per word instead of
  * 10 with extraction, compare and exec masks. */
 typedef __attribute__((address_space(3))) unsigned bl_lds_u32;
+/* What the range-test-free form rests on, checked where it can be: the histogram is the LAST object of the
+ * workgroup's LDS (static_asserts at the two kernels that use it; k_pcm_scan also compares its static LDS size at
+ * run time), so that 4 * bin >= 4 * BL_HIST_BINS lies behind the allocation or in the allocator's slack, where
+ * nothing lives.  -DBL_AMD_CHECKED_HIST (make XDEFS=-DBL_AMD_CHECKED_HIST) builds the kernels with the range compare
+ * instead: for debuggers and sanitizers that arm the LDS out-of-range trap. */
 __device__ __forceinline__ void scan_hist_word(unsigned w, unsigned lds_base) {
+#ifdef BL_AMD_CHECKED_HIST
+  const unsigned b0 = (unsigned)((int)(short)(w & 0xFFFFu) + BL_HIST_BINS / 2);
+  const unsigned b1 = (unsigned)((int)(short)(w >> 16) + BL_HIST_BINS / 2);
+  bl_lds_u32 *h = (bl_lds_u32 *)(size_t)lds_base;
+  if (b0 < BL_HIST_BINS) __hip_atomic_fetch_add(h + b0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (b1 < BL_HIST_BINS) __hip_atomic_fetch_add(h + b1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return;
+#endif
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   us2 v;
   __builtin_memcpy(&v, &w, 4);
@@ -122,6 +135,7 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const int16_t *__restrict__ pc
                                                   const bl_dsong *__restrict__ songs,
                                                   bl_dstats *stats, unsigned *hist) {
   __shared__ unsigned lh[BL_HIST_BINS]; /* the only LDS of this kernel: nothing lies behind it */
+  if (__builtin_amdgcn_groupstaticsize() != sizeof lh) __builtin_trap(); /* somebody added LDS: see scan_hist_word */
   const int tid = threadIdx.x;
   const bl_dsong sg = songs[blockIdx.y];
   const int16_t *p = pcm + sg.pcm_off;
@@ -455,6 +469,9 @@ typedef bl_c2<bl_f2> c2p; /* a complex number per frame of the pair */
 #define BL_FREQ_SCAN_LDS_BYTES (BL_FREQ_HIST_OFF(BL_FREQ_SCAN_WAVES) + 4 * BL_HIST_BINS) /* k_freq_scan: 159.1 KB */
 /* row stride of the power staging: 2 rows = 16 banks (mod 32) apart, so the two 16-lane groups
  * that share a 32-lane store group land on disjoint banks */
+static_assert(BL_FREQ_HIST_OFF(BL_FREQ_SCAN_WAVES) + 4 * BL_HIST_BINS == BL_FREQ_SCAN_LDS_BYTES &&
+                  BL_FREQ_SCAN_LDS_BYTES <= 160 * 1024,
+              "k_freq_scan: the histogram must be the last object of the workgroup's LDS (scan_hist_word)");
 #define BL_FREQ_SROW 264
 
 /* cross-lane move of a pair of floats through DPP (two 32-bit moves); CTRL 0x140 = row_mirror,
@@ -1942,7 +1959,7 @@ int blk_analyze(const blk_analyze_args &a) {
    *            amplitude kernel took the CUs first and the tail ran after it, not beside it);
    *   separate the tail goes to the side stream, the main stream runs the short amplitude kernel and then the wide
    *            frequency pass (launched after that pass, the tail started ~60 ms late). */
-  bool tail_async = false;
+  bool tail_async = false, head_async = false;
   hipStream_t rest_stream = stream; /* where the amplitude kernel and the frequency finish go */
   if (what & 4) {
     const int fir_mode = blk_fir_mode();
@@ -1979,7 +1996,15 @@ int blk_analyze(const blk_analyze_args &a) {
     const bool side = (what & 3) && a.side;
     auto launch_tail = [&](int first, int count, bool last) -> int {
       hipStream_t ts = stream;
-      if (side && fused && last) {
+      if (side && !last) {
+        /* the long songs of a mixed batch: their tail goes to the second side stream, behind its own event, and runs
+         * under the window kernel of the rest (on the first side stream it would stand in front of the amplitude
+         * kernel and the frequency finish, which only wait for the window kernel behind this one) */
+        BL_HIP_CHECK(hipEventRecord(a.ev_head, stream));
+        BL_HIP_CHECK(hipStreamWaitEvent(a.side2, a.ev_head, 0));
+        ts = a.side2;
+        head_async = true;
+      } else if (side && fused) {
         /* the tail stays here; the rest waits on the side stream for the window kernel in front of it */
         BL_HIP_CHECK(hipEventRecord(a.ev_env, stream));
         BL_HIP_CHECK(hipStreamWaitEvent(a.side, a.ev_env, 0));
@@ -2000,7 +2025,7 @@ int blk_analyze(const blk_analyze_args &a) {
      * launched behind the window kernel of the whole batch it outlasts the frequency pass it is meant to hide
      * behind.  The long songs [0, n_head) get their own window launch, and their tail runs on the side stream
      * under the window kernel of the rest. */
-    const int n_head = (a.n_head > 0 && a.n_head < n_songs && side) ? a.n_head : 0;
+    const int n_head = (a.n_head > 0 && a.n_head < n_songs && side && a.side2) ? a.n_head : 0;
     if (n_head) {
       if (launch_env(0, n_head, a.max_n) != BL_OK || launch_tail(0, n_head, false) != BL_OK) return BL_UNEXPECTED;
       if (launch_env(n_head, n_songs - n_head, a.max_n_rest) != BL_OK ||
@@ -2029,6 +2054,10 @@ int blk_analyze(const blk_analyze_args &a) {
   if (tail_async) {
     BL_HIP_CHECK(hipEventRecord(a.ev_tail, a.side));
     BL_HIP_CHECK(hipStreamWaitEvent(stream, a.ev_tail, 0));
+  }
+  if (head_async) {
+    BL_HIP_CHECK(hipEventRecord(a.ev_tail2, a.side2));
+    BL_HIP_CHECK(hipStreamWaitEvent(stream, a.ev_tail2, 0));
   }
   if (what == 7) hipLaunchKernelGGL(k_force, dim3(tb64), dim3(64), 0, stream, a.results, n_songs);
   BL_HIP_CHECK(hipGetLastError());
@@ -2082,7 +2111,7 @@ int blk_pairwise(hipStream_t s, const struct force_vector_s *d_vecs, int n, int 
  * (a quarter of them within 2^-4..2^16, where force vectors live), dot = u * sqrt(na nb) with u in [-1, 1], and for
  * each such triple the 8 neighbouring floats of dot.  counts: [0] triples, [1] triples the fast path accepts,
  * [2] accepted triples whose float differs from the plain expression's (must be 0), [3] largest |q' - q| seen,
- * in ulp of the double quotient (bound: 3.5), [4] triples whose q lies within 64 ulp of a float rounding
+ * in ulp of the double quotient (provable bound: < 6), [4] triples whose q lies within 64 ulp of a float rounding
  * boundary, [5] of those, how many the unguarded (float)q' would get wrong. */
 __global__ __launch_bounds__(256) void k_cos_sweep(unsigned long long seed, int per_thread, unsigned long long *counts) {
   unsigned long long st = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * 256ull + threadIdx.x + 1);

@@ -84,6 +84,8 @@ struct blk_analyze_args {
   bl_tables tb;
   hipStream_t stream, side;  /* side == nullptr: envelope tail on `stream` */
   hipEvent_t ev_env, ev_tail;
+  hipStream_t side2 = nullptr; /* mixed lengths: the long songs' tail (nullptr: no separate launch for them) */
+  hipEvent_t ev_head = nullptr, ev_tail2 = nullptr;
   blk_mark_fn mark;          /* may be nullptr */
   void *mark_user;
 };

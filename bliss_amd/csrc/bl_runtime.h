@@ -49,6 +49,8 @@ struct bl_amd_ctx {
   int group_songs = BL_GROUP_SONGS_MAX;
   hipStream_t side = nullptr; /* envelope tail runs here, beside the frequency pass */
   hipEvent_t ev_env = nullptr, ev_tail = nullptr;
+  hipStream_t side2 = nullptr; /* mixed lengths: the tail of the long songs, under the window kernel of the rest */
+  hipEvent_t ev_head = nullptr, ev_tail2 = nullptr;
   hipEvent_t ev_ws = nullptr; /* end of the last launch group that used the workspace */
   bool ws_used = false;
   long long last_env_total = 0;

@@ -93,8 +93,11 @@ int ctx_init(bl_amd_ctx *c, int device) {
     c->group_songs = g < 1 ? 1 : (g > BL_GROUP_SONGS_MAX ? BL_GROUP_SONGS_MAX : g);
   }
   BL_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  BL_HIP_CHECK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
   BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_env, hipEventDisableTiming));
   BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+  BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming));
+  BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_tail2, hipEventDisableTiming));
   BL_HIP_CHECK(hipEventCreateWithFlags(&c->ev_ws, hipEventDisableTiming));
   for (int k = 0; k < BL_PIN_SLOTS; ++k)
     BL_HIP_CHECK(hipEventCreateWithFlags(&c->ring[k].ev, hipEventDisableTiming));
@@ -144,8 +147,13 @@ void ctx_release(bl_amd_ctx *c) {
   if (c->tables_mem) (void)hipFree(c->tables_mem);
   c->tables_mem = nullptr;
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->side2) (void)hipStreamDestroy(c->side2);
   if (c->ev_env) (void)hipEventDestroy(c->ev_env);
   if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+  if (c->ev_head) (void)hipEventDestroy(c->ev_head);
+  if (c->ev_tail2) (void)hipEventDestroy(c->ev_tail2);
+  c->side2 = nullptr;
+  c->ev_head = c->ev_tail2 = nullptr;
   if (c->ev_ws) (void)hipEventDestroy(c->ev_ws);
   c->side = nullptr;
   c->ev_env = c->ev_tail = c->ev_ws = nullptr;
@@ -349,6 +357,9 @@ int blr_analyze_device(bl_amd_ctx *c, const int16_t *d_pcm, const bl_amd_song_de
 #endif
     a.ev_env = c->ev_env;
     a.ev_tail = c->ev_tail;
+    a.side2 = a.side ? c->side2 : nullptr;
+    a.ev_head = c->ev_head;
+    a.ev_tail2 = c->ev_tail2;
     a.mark = c->prof ? mark_cb : nullptr;
     a.mark_user = c;
     if (blk_analyze(a) != BL_OK) return BL_UNEXPECTED;
@@ -957,7 +968,8 @@ int bl_amd_analyze_files(const char *const *filenames, int n_files, struct bl_so
   /* The decoders run ahead of the wave being analysed by at most AHEAD_BYTES of decoded PCM (and AHEAD_FILES
    * files): a byte bound, because a file bound alone lets 768 ten-minute songs (40 GB) pile up on the host.
    * The file the consumer is waiting for is always taken, whatever the budget says, so the two cannot deadlock. */
-  const size_t AHEAD_BYTES = 3 * WAVE_BYTES;
+  const size_t AHEAD_BYTES = 3 * WAVE_BYTES; /* bounds the READ-AHEAD only: with keep_pcm the caller keeps every decoded
+                                               * sample_array (include/bliss_amd.h), and that total is the caller's */
   const int WAVE_FILES = 512, AHEAD_FILES = 768; /* AHEAD_FILES >= WAVE_FILES: a wave never waits for a file the decoders may not take */
 
   std::mutex mu;

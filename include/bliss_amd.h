@@ -104,7 +104,10 @@ int bl_amd_ctx_analyze_batch_host(bl_amd_ctx *ctx, const int16_t *const *h_pcm,
  * through the pinned-staging path of bl_amd_analyze_batch_host, so decoding, transfer and
  * analysis overlap.  songs[i] (caller-owned, uninitialised is fine) is filled exactly as
  * bl_analyze(filenames[i], &songs[i]) fills it — release each with bl_free_song; with
- * keep_pcm == 0 the sample_array is freed (and NULL) once the song has been analysed.
+ * keep_pcm == 0 the sample_array is freed (and NULL) once the song has been analysed.  With keep_pcm != 0 every decoded
+ * sample_array stays allocated until the caller frees it: the library bounds its decoders' read-ahead (3 GiB of PCM
+ * not yet analysed), not the total, which is the caller's — a corpus that does not fit in host memory has to be
+ * analysed with keep_pcm == 0 or in slices.
  * codes (optional, n_files ints) receives what bl_analyze would have returned for the file:
  * BL_LOUD / BL_CALM / BL_UNKNOWN or BL_UNEXPECTED.  Returns the number of files analysed, or
  * BL_UNEXPECTED if the device path itself failed.  Blocking. */
@@ -245,7 +248,7 @@ int bl_amd_selftest_sqrt(uint64_t counts[3]);
 /* Same for the cosine matrix's guarded quotient (bl_cos.h): at least `triples` pseudo-random (dot, |a|^2, |b|^2)
  * on the device against the plain expression of ref src/analyze.c:135-140.  counts: [0] triples tried, [1] taken by
  * the fast path, [2] fast results that differ from the plain expression (must be 0), [3] largest difference of
- * the two double quotients in ulp (bound 3.5, guard 16), [4] triples within 64 ulp of a float rounding boundary,
+ * the two double quotients in ulp (provable bound < 6, guard 16), [4] triples within 64 ulp of a float rounding boundary,
  * [5] of those, how many an unguarded fast path would have got wrong. */
 int bl_amd_selftest_cos(uint64_t counts[6], uint64_t triples);
 
@@ -277,7 +280,7 @@ int bl_amd_set_fir_mode(int mode);
 int bl_amd_fir_mode(void);
 
 /* Per-kernel device time, measured with hipEvents on the launch stream while
- * profiling is on (bench.py's roofline leg).  name is one of "pcm_scan",
+ * profiling is on (bench.py's roofline leg).  name is one of "pcm_scan", "freq_scan",
  * "amp_finish", "freq_frames", "freq_finish", "env_windows", "env_tail",
  * "distance"; returns accumulated milliseconds and the launch count since the
  * last reset, or -1 for an unknown name. */

@@ -568,13 +568,13 @@ def test_cosine_matrix_bit_exact_including_degenerate_vectors(gpu_lib, oracle):
 def test_guarded_cosine_quotient_sweep(gpu_lib):
     """bl_cos.h is not taken on trust: 2^33 pseudo-random (dot, |a|^2, |b|^2) triples — each random dot with its
     eight neighbouring floats — on the device against the plain expression: no accepted fast result differs, the
-    double quotients never differ by more than the 3.5 ulp the guard of 16 is built on, and the sweep does meet
+    double quotients never differ by more than the 6 ulp that six roundings allow (the guard is 16), and the sweep does meet
     the float rounding boundaries the guard exists for (where the unguarded form is wrong)."""
     counts = (C.c_uint64 * 6)()
     assert gpu_lib.bl_amd_selftest_cos(counts, 1 << 33) == 0
     n, n_fast, bad, max_ulp, near, near_bad = (int(x) for x in counts)
     assert n >= 1 << 33 and bad == 0, (n, bad)
-    assert n_fast > 0.999 * n * 0.5 and max_ulp <= 4, (n_fast, max_ulp)   # zero / tiny dots and norms take the plain form
+    assert n_fast > 0.999 * n * 0.5 and max_ulp <= 6, (n_fast, max_ulp)   # zero / tiny dots and norms take the plain form
     assert near > 100, near
     print("cosine sweep:", dict(triples=n, fast=n_fast, max_ulp=max_ulp, near_boundary=near, unguarded_wrong=near_bad))
 
