@@ -122,6 +122,12 @@ body("bfe_u32", [f"v_bfe_u32 v{64 + (i % 32)}, v{32 + (i % 32)}, 16, 16" for i i
 body("mad_u64_u32", [f"v_mad_u64_u32 v[{64 + 2 * (i % 16)}:{65 + 2 * (i % 16)}], vcc, v{32 + (i % 32)}, v6, v[{64 + 2 * (i % 16)}:{65 + 2 * (i % 16)}]" for i in range(64)], note="32 x 32 + 64 -> 64")
 body("add3_u32", [f"v_add3_u32 v{64 + (i % 32)}, v{32 + (i % 32)}, v6, v{64 + (i % 32)}" for i in range(64)])
 body("addc_u64", [x for i in range(32) for x in (f"v_add_co_u32 v{64 + 2 * (i % 16)}, vcc, v{64 + 2 * (i % 16)}, v6", f"v_addc_co_u32 v{65 + 2 * (i % 16)}, vcc, 0, v{65 + 2 * (i % 16)}, vcc")], note="64-bit add as add_co + addc")
+# for tools/energy_probe.py (socket power per kind of work): pure LDS streams and a stream that issues nothing
+body("lds_read_b128", [f"ds_read_b128 v[{64 + 4 * (i % 8)}:{67 + 4 * (i % 8)}], v11" + (f" offset:{1024 * (i % 8)}" if i % 8 else "") for i in range(16)] + ["s_waitcnt lgkmcnt(0)"],
+     n_valu=16, note="16 ds_read_b128 then wait; per read")
+body("lds_write_b128", [f"ds_write_b128 v11, v[{32 + 4 * (i % 8)}:{35 + 4 * (i % 8)}]" + (f" offset:{1024 * (i % 8)}" if i % 8 else "") for i in range(16)] + ["s_waitcnt lgkmcnt(0)"],
+     n_valu=16, note="16 ds_write_b128 then wait; per write")
+body("idle_nop", ["s_nop 15"] * 64, note="nothing but s_nop: the clocked-but-idle baseline")
 REPEAT = {k: 4 for k in BODIES}
 for k in ("bpermute", "fma_with_bpermute", "fma_with_lds_xchg", "fir_serial", "fir_x2", "fir_x4"): REPEAT[k] = 2
 
@@ -178,6 +184,34 @@ int main(int argc, char **argv) {
   const int dur = 2000000, blocks = 256; /* shader cycles per run */
   unsigned *out; hipMalloc(&out, 4 * blocks * 16);
   std::vector<unsigned> h(blocks * 16);
+  /* `ubench_issue.bin <name> long <waves per SIMD> <seconds>`: ONE stream on every CU for seconds on end, so that the
+   * socket power and the shader clock settle and can be sampled from outside (tools/energy_probe.py); prints the
+   * wave-instructions per second the whole chip retired, by the wall clock */
+  if (argc > 4 && !strcmp(argv[2], "long")) {
+    const int w = atoi(argv[3]);
+    const double seconds = atof(argv[4]);
+    for (auto &bn : benches) {
+      if (strcmp(bn.name, argv[1])) continue;
+      hipFuncSetAttribute(reinterpret_cast<const void *>(bn.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      bn.fn<<<blocks, 256 * w, 100 * 1024>>>(out, 20000, 0);
+      hipDeviceSynchronize();
+      double passes = 0, ms_total = 0;
+      while (ms_total < 1e3 * seconds) {
+        hipEventRecord(e0);
+        bn.fn<<<blocks, 256 * w, 100 * 1024>>>(out, 1000000000, 0);   /* ~0.42 s of s_memtime ticks */
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpy(h.data(), out, 4 * blocks * 4 * w, hipMemcpyDeviceToHost);
+        for (int i = 0; i < blocks * 4 * w; ++i) passes += h[i];
+        ms_total += ms;
+      }
+      printf("{\"stream\": \"%s\", \"waves_per_simd\": %d, \"seconds\": %.3f, \"wave_instr_per_s\": %.6g, "
+             "\"instr_per_pass\": %d}\n", bn.name, w, ms_total / 1e3, passes * bn.n_instr / (ms_total / 1e3), bn.n_instr);
+    }
+    return 0;
+  }
   printf("%-22s %6s %4s  %14s  %s\n", "stream", "W/SIMD", "prio", "cyc/instr/SIMD", "share of the SIMD's instructions by wave age (oldest first) | note");
   for (auto &bn : benches) {
     if (argc > 1 && !strstr(bn.name, argv[1])) continue;
