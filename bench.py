@@ -844,7 +844,12 @@ def main():
                          "what": "each rank's own wall clock over the timed steps (the line's ms_per_step is the max) "
                                  "and its k_env_windows3 HIP-event average"},
             "device_state": dict(device_state, per_rank_sclk_mhz=[float(x) for x in per_rank[:, 2]],
-                                 per_rank_power_w=[float(x) for x in per_rank[:, 3]]),
+                                 per_rank_power_w=[float(x) for x in per_rank[:, 3]],
+                                 # the analysis runs against the socket power cap: what a song costs
+                                 joules_per_song=(float(per_rank[:, 3].sum()) * elapsed / (total_songs * args.steps)
+                                                  if float(per_rank[:, 3].min()) > 0 else None),
+                                 power_capped=(bool(device_state["power_w"]["p50"] > 0.9 * device_state["power_cap_w"])
+                                               if device_state.get("power_w") and device_state.get("power_cap_w") else None)),
             "other_configs": others,
             "roofline": roof,
         }
