@@ -367,6 +367,48 @@ def other_configs(lib, dev, main_songs, steps=3):
     return out
 
 
+def live_traffic(seconds, songs=1024, timeout=240):
+    """HBM traffic of the kernels, collected in THIS run: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE — separate
+    passes, --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) around one step of this script
+    over `songs` songs of the same shape, started as child processes after the parent has released its resident batch.
+    Returns {kernel: bytes per song} with the gfx950 corrections (FETCH_SIZE counts half of a wide coalesced streaming
+    read and is in KB; WRITE_SIZE is taken as is) or {"error": ...}: the caller falls back on the committed profile."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "no rocprofv3 on this box"}
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="bl_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--songs-per-gpu", str(songs), "--seconds", str(seconds), "--steps", "1",
+                   "--warmup", "0", "--no-cpu-baseline", "--verify", "0", "--no-mode0-pass", "--no-other-configs",
+                   "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}"}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                    v = float(row["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+                    acc[k] = acc.get(k, 0.0) + v
+        return {k: v / songs for k, v in acc.items()}
+    except (OSError, subprocess.TimeoutExpired, KeyError, ValueError) as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -471,6 +513,9 @@ def main():
                     help="skip the untimed extra pass in FIR mode 0 (profiling runs: one envelope launch per step)")
     ap.add_argument("--cpu-ladder", default="1,8,32,64,128,256",
                     help="concurrent oracle processes per rung of the CPU baseline (tests shorten it)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not collect roofline.traffic in this run (two rocprofv3 --pmc passes over 1 024 songs, N = 1 "
+                         "only, ~20 s): take the committed profile's figure")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the untimed-for-value legs on BASELINE configs[1] and configs[4] (profiling runs)")
     ap.add_argument("--verify", type=int, default=32,
@@ -769,6 +814,31 @@ def main():
                 others = other_configs(lib, dev, songs)
             except Exception as e:   # a diagnostic leg must never sink the line
                 others = {"error": f"{type(e).__name__}: {e}"}
+
+        # roofline.traffic collected in this run (N = 1; the resident batch is gone by now, the children fit)
+        if roof is not None and world == 1 and not args.no_live_traffic and not args.share_device:
+            try:
+                del corpus
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            lt = live_traffic(args.seconds, songs=min(1024, songs))
+            if "error" not in lt and lt.get("k_env_windows3"):
+                scale = 1.0   # bytes per song of this shape already
+                roof["traffic"] = lt["k_env_windows3"] * songs * scale
+                roof["traffic_error"] = None
+                roof["traffic_source"] = {"what": "collected in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass "
+                                                  "each (--kernel-trace only), around one step of this script over "
+                                                  f"{min(1024, songs)} songs of the same shape in a child process; bytes per song x the "
+                                                  "songs of the launch; gfx950 corrections of MI355X_MICROARCH.md",
+                                          "bytes_per_song_by_kernel": {k: v for k, v in sorted(lt.items())},
+                                          "committed_profile_for_comparison": prof.get("file"),
+                                          "committed_profile_traffic": prof.get("traffic")}
+                # the analysis kernels of a step (not the synthesis of the corpus, not the stand-alone 10 000^2 matrices)
+                step_b = sum(v for k, v in lt.items() if k.startswith("k_") and k not in ("k_synth", "k_pairwise"))
+                roof["whole_step_traffic_ratio"] = step_b / alg_bytes_song
+            else:
+                roof["traffic_source"]["live_collection_error"] = lt.get("error", "no k_env_windows3 row")
 
         # BASELINE config 4: standalone 10 000 x 10 000 bl_distance matrix on one GPU
         g = torch.Generator(device="cpu").manual_seed(4)

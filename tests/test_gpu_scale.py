@@ -115,6 +115,11 @@ def test_bench_under_torchrun_runs_rccl_and_verifies(gpu_lib):
     oc = line["other_configs"]
     assert oc["configs1"]["results_ok"] is True and oc["configs4_mixed"]["results_ok"] is True
     assert oc["configs1"]["songs_per_s"] > 0 and oc["configs4_mixed"]["verified_songs"] >= 3
+    # roofline.traffic is collected in the run itself (two rocprofv3 --pmc passes in child processes): within a few
+    # per cent of the algorithmic bytes for the window kernel, and the line says where it came from
+    rf = line["roofline"]
+    assert "collected in this run" in rf["traffic_source"]["what"], rf["traffic_source"]
+    assert 0.95 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.25, rf["traffic"]
 
 
 def test_bench_self_launch(gpu_lib):
@@ -122,7 +127,7 @@ def test_bench_self_launch(gpu_lib):
     --launch takes the N = 1 case through the same self-launch path N > 1 uses (ranks started
     under torch.distributed.run on 127.0.0.1, RCCL process group, one JSON line on stdout)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch", "--steps", "2", "--warmup", "1",
-           "--songs-per-gpu", "16", "--seconds", "20", "--no-cpu-baseline", "--verify", "4"]
+           "--songs-per-gpu", "16", "--seconds", "20", "--no-cpu-baseline", "--verify", "4", "--no-live-traffic"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -203,7 +208,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu_lib):
     the ranks' shards and seeds (rank 1 analyses songs 24..47), the gather order, row blocks that
     start at row 24, the oracle check shared out over the ranks, results_ok reduced over both."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "1",
-           "--songs-per-gpu", "24", "--seconds", "20", "--cpu-ladder", "1,8", "--verify", "8"]
+           "--songs-per-gpu", "24", "--seconds", "20", "--cpu-ladder", "1,8", "--verify", "8", "--no-live-traffic"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

@@ -13,8 +13,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BDEF="python bench.py --no-cpu-baseline --no-other-configs"
-BPMC="python bench.py --songs-per-gpu $PSONGS --steps 1 --warmup 0 --no-cpu-baseline --verify 0 --no-mode0-pass --no-other-configs"
+BDEF="python bench.py --no-cpu-baseline --no-other-configs --no-live-traffic"
+BPMC="python bench.py --songs-per-gpu $PSONGS --steps 1 --warmup 0 --no-cpu-baseline --verify 0 --no-mode0-pass --no-other-configs --no-live-traffic"
 (cd $ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BDEF \
    > $OUT/bench_8192songs_under_rocprof.json 2> $OUT/trace.log)
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)

@@ -19,7 +19,7 @@ for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
          "SQ_WAVES SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INSTS_FLAT"; do
   i=$((i+1))
   (cd $ROOT && BL_AMD_NO_SIDE=1 timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/p$i -- \
-     python bench.py --songs-per-gpu $SONGS --steps 1 --warmup 0 --no-cpu-baseline --verify 0 --no-mode0-pass --no-other-configs > $OUT/p$i.log 2>&1)
+     python bench.py --songs-per-gpu $SONGS --steps 1 --warmup 0 --no-cpu-baseline --verify 0 --no-mode0-pass --no-other-configs --no-live-traffic > $OUT/p$i.log 2>&1)
 done
 python - $OUT $PAT <<'PY'
 import csv,sys,glob,collections
