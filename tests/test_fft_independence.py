@@ -11,7 +11,7 @@ the reference's recording and the committed synthetic cases under all of them:
     (ref tests/test_analyze.c:5-11), and the reason the parity tests give `frequency` and `force` that absolute term
     on top of 1e-4 relative.
 profiles/r05_fft_independence.json (tools/fft_independence.py) has the same for every case with the defining sum
-and for 96 more songs."""
+and for 480 more songs (10.1 million windows, 0 differences)."""
 import ctypes as C
 import json
 import os
