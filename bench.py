@@ -174,16 +174,22 @@ def cpu_baseline(ladder_levels=(1, 8, 32, 64, 128, 256)):
 
     ladder = [level(1, 2, 9000)]
     one = ladder[0]["songs_per_s"]
+    # rungs beyond four times the cgroup CPU quota only measure oversubscription (round 5: 44 songs/s at 32-64 processes
+    # under a quota of 16, 30 at 256, 20 s of the driver's run): the ladder stops there, and as soon as two rungs in a
+    # row are slower than the best so far
+    quota = limits.get("cgroup_cpu_quota")
+    top = min(avail, int(4 * quota)) if quota else avail
+    slower = 0
     for procs in [p for p in ladder_levels if p > 1]:
-        if procs > max(avail, 1):
+        if procs > max(top, 1) or slower >= 2:
             break
         ladder.append(level(procs, 1, 9100 + procs))
-    if ladder[-1]["processes"] != avail and avail > 1 and avail not in ladder_levels and len(ladder_levels) > 2:
+        slower = slower + 1 if ladder[-1]["songs_per_s"] < max(l["songs_per_s"] for l in ladder[:-1]) else 0
+    if not quota and ladder[-1]["processes"] != avail and avail > 1 and avail not in ladder_levels and len(ladder_levels) > 2 and slower < 2:
         ladder.append(level(avail, 1, 9700))
     best = max(l["songs_per_s"] for l in ladder)
     eff = next(l["processes"] for l in ladder if l["songs_per_s"] >= 0.9 * best)
     # a cgroup CPU quota below that count is the real amount of CPU the processes shared
-    quota = limits.get("cgroup_cpu_quota")
     if quota and quota < eff:
         eff = int(round(quota))
     model = ""
@@ -216,6 +222,8 @@ def cpu_baseline(ladder_levels=(1, 8, 32, 64, 128, 256)):
                       f"{[l['processes'] for l in ladder]} concurrent single-threaded processes "
                       "(1 song each, 2 at the first level), analysis time only; cores = min(smallest "
                       "process count within 10 % of the best throughput, cgroup CPU quota)",
+            "sample_short": f"{songs} synthetic 3-min songs over {'/'.join(str(l['processes']) for l in ladder)} concurrent "
+                            "1-thread oracle processes",
             "ladder": ladder, "limits": limits, "cpu_model": model,
             "one_core_songs_per_s": one, "scaling_vs_one_core": best / one if one else None}
 
@@ -250,7 +258,11 @@ def verify_songs(res, picks, seed_first, seconds):
     return ok, details
 
 
-F64_ISSUE_TWAVEINSTR_S = 0.56     # measured f64 VALU issue rate, T wave-instr/s (tools/ubench_rate.hip; = 71.5 TF as FMA)
+F64_ISSUE_TWAVEINSTR_S = 0.56     # measured f64 VALU issue rate, T wave-instr/s (tools/ubench_rate.hip; = 71.5 TF as FMA):
+                                  # the rate at the clock the power cap leaves the kernel (1 024 SIMDs x ~2.19 GHz / 4)
+F64_ISSUE_NOMINAL_TWAVEINSTR_S = 256 * 4 * 2.4e9 / 4 / 1e12   # 0.6144: the same pipe at the specified 2.4 GHz (78.6 TF as FMA;
+                                  # /opt/skills/guides/MI355X_MICROARCH.md chip table: 256 CU x 4 SIMD, 2 400 MHz)
+LINE_BYTES_MAX = 1700             # the printed line: the driver keeps the last 2 000 bytes of stdout + stderr
 # f64 wave-instructions per window the arithmetic needs, by FIR mode: mode 0 the
 # reference's unfused FIR (25 ops/output) and two-op normalisation; 1: 17 ops/output; 2: no normalisation
 F64_FLOOR_INSTR_PER_WINDOW = {0: 289, 1: 255, 2: 247}
@@ -409,6 +421,78 @@ def live_traffic(seconds, songs=1024, timeout=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _sig(x, sig=5):
+    """A float of the printed line, rounded to `sig` significant digits (None for NaN / inf)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{sig}g}")
+
+
+def compact_line(d, details_path=None, limit=LINE_BYTES_MAX):
+    """The ONE line on stdout, from the full record `d` (which goes to bench_details.json).  The driver keeps the last
+    2 000 bytes of stdout + stderr (BENCH_r05.json: a 21 KB line could not be parsed), so the line stays under `limit`
+    bytes: the contract's keys first, then scalars in the order in which they are given up if the line were too long."""
+    rf, cb = d.get("roofline") or {}, d.get("cpu_baseline") or {}
+    cfg = d.get("config") or {}
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                  "scaling", "vs_baseline", "dtype", "data")}
+    for k in ("value", "ms_per_step"):
+        line[k] = _sig(line[k], 7)
+    line["config"] = {"workload": cfg.get("workload_short") or cfg.get("workload"), "songs_per_gpu": cfg.get("songs_per_gpu"),
+                      "parallelism": cfg.get("parallelism"), "fir_mode": (d.get("fir_modes") or {}).get("timed_mode")}
+    line["results_ok"], line["verified_songs"] = d.get("results_ok"), d.get("verified_songs")
+    line["roofline"] = None if not rf else {
+        "bound": rf.get("bound"), "kernel": rf.get("kernel"), "achieved": _sig(rf.get("achieved")), "peak": rf.get("peak"),
+        "unit": rf.get("unit"), "frac": _sig(rf.get("frac")), "traffic": _sig(rf.get("traffic"), 6),
+        "traffic_src": ("live_pmc" if "collected in this run" in str((rf.get("traffic_source") or {}).get("what", ""))
+                        else ((rf.get("traffic_source") or {}).get("file") if rf.get("traffic") else None)),
+        "ms_avg_launch": _sig(rf.get("ms_avg_launch")), "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
+        "frac_of_f64_floor": _sig(rf.get("frac_of_f64_floor"), 4),
+        "frac_of_f64_floor_nominal": _sig(rf.get("frac_of_f64_floor_nominal"), 4),
+        "whole_step_traffic_ratio": _sig(rf.get("whole_step_traffic_ratio"), 4),
+        "frac_fir_mode0": _sig(rf.get("frac_fir_mode0"), 4)}
+    line["cpu_baseline"] = {"value": _sig(cb.get("value"), 4), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                            "kind": cb.get("kind"), "sample": cb.get("sample_short") or cb.get("sample"),
+                            "cpu_model": cb.get("cpu_model"), "one_core_songs_per_s": _sig(cb.get("one_core_songs_per_s"), 4)}
+    oc, ds = d.get("other_configs") or {}, d.get("device_state") or {}
+    fs = (rf.get("other_pcm_pass") or {}) if rf else {}
+    strict = ((d.get("verification") or {}).get("n_failing_strict_1e-4_rel") or {})
+    optional = [   # given up from the END of this list if the line were longer than `limit`
+        ("value_fir_mode0", _sig(d.get("value_fir_mode0"), 6)),
+        ("ms_per_step_fir_mode0", _sig(d.get("ms_per_step_fir_mode0"), 6)),
+        ("distance_matrix_10k_s", _sig(d.get("distance_matrix_10k_s"), 4)),
+        ("rehearsal", True if d.get("rehearsal") else None),
+        ("details", os.path.basename(details_path) if details_path else None),
+        ("other_configs", None if not oc else ({"error": str(oc["error"])[:80]} if "error" in oc else {
+            "configs1_ms": _sig((oc.get("configs1") or {}).get("ms_per_batch"), 4),
+            "configs1_songs_per_s": _sig((oc.get("configs1") or {}).get("songs_per_s"), 4),
+            "configs4_ms": _sig((oc.get("configs4_mixed") or {}).get("ms_per_batch"), 4),
+            "configs4_songs_per_s": _sig((oc.get("configs4_mixed") or {}).get("songs_per_s"), 4),
+            "ok": bool((oc.get("configs1") or {}).get("results_ok") and (oc.get("configs4_mixed") or {}).get("results_ok"))})),
+        ("device_state", {"sclk_mhz": (ds.get("sclk_mhz") or {}).get("mean"), "power_w": (ds.get("power_w") or {}).get("mean"),
+                          "power_cap_w": ds.get("power_cap_w"), "joules_per_song": _sig(ds.get("joules_per_song"), 3)}),
+        ("per_rank_ms", [_sig(x, 5) for x in (d.get("per_rank") or {}).get("ms_per_step", [])] if (d.get("n_gpus") or 1) > 1 else None),
+        ("collective", (d.get("collective") or {}).get("backend")),
+        ("strict_1e-4_rel_failures", sum(strict.values()) if strict else None),
+        ("freq_scan", None if not fs else {"ms": _sig(fs.get("ms_avg_launch"), 4), "frac_hbm": _sig(fs.get("frac"), 3)}),
+        ("distance_matrix_10k_frac_hbm", _sig(d.get("distance_matrix_10k_frac_hbm"), 3)),
+        ("cosine_matrix_10k_s", _sig(d.get("cosine_matrix_10k_s"), 4)),
+        ("whole_path_frac_hbm", _sig(d.get("whole_path_frac_hbm"), 3)),
+    ]
+    optional = [(k, v) for k, v in optional if v is not None]
+    while True:
+        out = dict(line, **dict(optional))
+        if len(json.dumps(out, separators=(",", ":"))) <= limit or not optional:
+            return out
+        optional.pop()
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -518,6 +602,9 @@ def main():
                          "only, ~20 s): take the committed profile's figure")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the untimed-for-value legs on BASELINE configs[1] and configs[4] (profiling runs)")
+    ap.add_argument("--details-out", default="",
+                    help="where the full record goes (verification per song, per-kernel times, CPU ladder, traffic by "
+                         "kernel ...; default: bench_details.json next to this script); stdout carries the compact line only")
     ap.add_argument("--verify", type=int, default=32,
                     help="songs of the resident batch re-analysed by the CPU oracle after the timed region")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -673,32 +760,46 @@ def main():
     per_rank = per_rank.cpu().numpy()
 
     res = corpus.fetch()
-    # Untimed: the same batch once more in FIR mode 0 (the reference's operation order, window energies bit-identical
-    # to the CPU oracle) — what the timed default (mode 2: fused taps, normalisation folded in)
-    # buys, and whether any integer or feature of this batch depends on it.
+    # Outside the timed region: the same steps in FIR mode 0 (the reference's operation order, window energies
+    # bit-identical to the CPU oracle) — what the timed default (mode 2: fused taps, normalisation folded in; DESIGN.md
+    # section 4.1) buys, measured on real steps (one warm-up, then min(K, 3) steps between fences, max over ranks), and
+    # whether any integer or feature of this batch depends on the mode.
     fir_active = int(lib.bl_amd_fir_mode())
     fir_report = {"timed_mode": fir_active}
     if fir_active != 0 and not args.no_mode0_pass:
         lib.bl_amd_set_fir_mode(0)
+        n0 = max(1, min(args.steps, 3))
+        step()
+        fence()
         lib.bl_amd_profile_reset()
         lib.bl_amd_profile(1)
-        corpus.analyze()
-        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(n0):
+            step()
+        fence()
+        el0 = time.perf_counter() - t1
         lib.bl_amd_profile(0)
-        n0 = C.c_int(0)
-        ms0 = lib.bl_amd_profile_ms(b"env_windows", C.byref(n0))
+        if dist.is_initialized():
+            t = torch.tensor([el0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el0 = float(t.item())
+        c0 = C.c_int(0)
+        ms0 = lib.bl_amd_profile_ms(b"env_windows", C.byref(c0))
         res0 = corpus.fetch()
         lib.bl_amd_set_fir_mode(fir_active)
+        step()          # leave the resident results (and the gathered vectors the checks below read) in the timed mode
+        fence()
         ints = ("start", "end", "mean", "variance", "n_frames", "nb_frames", "n_windows", "beat", "calm_or_loud", "status")
         flts = ("tempo", "amplitude", "frequency", "attack", "force")
         fir_report.update({
-            "mode0_env_windows_ms": ms0 / max(n0.value, 1),
+            "mode0_steps": n0, "mode0_ms_per_step": 1e3 * el0 / n0,
+            "mode0_env_windows_ms": ms0 / max(c0.value, 1),
             "timed_mode_env_windows_ms": kern["env_windows"]["ms_avg"],
             "songs_with_an_integer_differing_from_mode0": int(sum(np.count_nonzero(res[k] != res0[k]) for k in ints)),
             "songs_with_a_feature_bit_differing_from_mode0": int(sum(np.count_nonzero(res[k].view(np.int32) != res0[k].view(np.int32))
                                                                    for k in flts)),
-            "what": "mode 0 = the reference's unfused FIR, one untimed pass over the same resident batch after the "
-                    "timed region; bl_amd_set_fir_mode(0) selects it"})
+            "what": "mode 0 = the reference's unfused FIR: real steps over the same resident batch after the timed "
+                    "region (measured, not derived); bl_amd_set_fir_mode(0) selects it"})
     ok = bool(np.all(res["status"] == 0) and np.all(np.isfinite(res["force"])))
     # the gathered vectors are the analysed ones, rank-major, and this rank's rows are distances
     ok = ok and bool(torch.equal(all_vecs[my_first:my_first + songs].cpu(),
@@ -775,8 +876,12 @@ def main():
                     "algorithmic_bytes_per_launch": launch_bytes,
                     "fir_mode": fir_mode,
                     "frac_of_f64_floor": floor_s / t_launch,
+                    # the same instruction count at the specified clock (2.4 GHz, 0.6144 T wave-instr/s = 78.6 TF): the
+                    # figure that does not move with the power cap's clock
+                    "frac_of_f64_floor_nominal": windows * floor_instr / (F64_ISSUE_NOMINAL_TWAVEINSTR_S * 1e12) / t_launch,
                     "f64_floor": {"wave_instr_per_window": floor_instr,
                                   "issue_rate_Twaveinstr_per_s": F64_ISSUE_TWAVEINSTR_S,
+                                  "issue_rate_nominal_Twaveinstr_per_s": F64_ISSUE_NOMINAL_TWAVEINSTR_S,
                                   "what": "static: the f64 operations the arithmetic of this FIR mode needs per "
                                           "window (DESIGN.md section 4.1) at the measured f64 issue rate"},
                     "secondary_f64_valu": valu,
@@ -792,13 +897,13 @@ def main():
                 roof["frac_of_f64_floor_fir_mode0"] = (windows * F64_FLOOR_INSTR_PER_WINDOW[0] / (F64_ISSUE_TWAVEINSTR_S * 1e12)
                                                        / (1e-3 * fir_report["mode0_env_windows_ms"]))
         whole_path_gbs = value / world * alg_bytes_song / 1e9
-        # the reference's operation order (FIR mode 0): the step with the mode-0 window kernel's time in place of the
-        # timed mode's — the strict-order throughput beside `value`
+        # the reference's operation order (FIR mode 0): real steps timed in that mode after the timed region — the
+        # strict-order throughput beside `value`
         value_mode0 = ms_per_step_mode0 = None
         if fir_active == 0:
             value_mode0, ms_per_step_mode0 = value, ms_per_step
-        elif fir_report.get("mode0_env_windows_ms") and dom["ms_avg"]:
-            ms_per_step_mode0 = ms_per_step + fir_report["mode0_env_windows_ms"] - dom["ms_avg"]
+        elif fir_report.get("mode0_ms_per_step"):
+            ms_per_step_mode0 = fir_report["mode0_ms_per_step"]
             value_mode0 = total_songs / (1e-3 * ms_per_step_mode0)
         # the literal north_star bar, per field: |gpu - oracle| <= 1e-4 |oracle| with no absolute term
         strict = {k: int(sum(1 for d in verify_details if not d["rel_err_by_field"][k] <= 1e-4))
@@ -882,6 +987,9 @@ def main():
                                      "all-gather of force vectors + row-block distance matrix; envelope FIR mode "
                                    + f"{fir_active} (library default; mode 0 = the reference's operation order, timed beside "
                                      "it in fir_modes)",
+                       "workload_short": f"configs[2] shard: {songs} synthetic {args.seconds}-s 44.1 kHz s16 stereo songs/GPU resident "
+                                         f"({songs * song_bytes / 1e9:.1f} GB), {total_songs} total; step = analyze + all-gather + "
+                                         "row-block distance",
                        "songs_per_gpu": songs, "song_samples": song_samples, "parallelism": f"shard{world}",
                        "generator": "integer-only device synth, seeds = global song index"},
             "distance_matrix_10k_s": dm_s,
@@ -928,16 +1036,25 @@ def main():
         if args.no_cpu_baseline:
             line["cpu_baseline"] = {"value": None, "unit": "songs/s", "cores": None, "kind": "port",
                                     "sample": "not measured in this run (--no-cpu-baseline): see the N = 1 line of the "
-                                              "same box, BENCH_r*.json"}
+                                              "same box, BENCH_r*.json", "sample_short": "not measured (--no-cpu-baseline)"}
         else:
             try:
                 line["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in args.cpu_ladder.split(",")))
                 if world > 1:
                     line["cpu_baseline"]["sample"] += f"; timed on rank 0 of {world} after the timed region, the other ranks parked"
+                    line["cpu_baseline"]["sample_short"] += f"; rank 0 of {world}"
             except Exception as e:  # the baseline must never sink the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "songs/s", "cores": None,
                                         "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(line), flush=True)
+        # everything above goes to a side file; stdout gets ONE compact line (the driver keeps the last 2 000 bytes)
+        details_path = args.details_out or os.path.join(ROOT, "bench_details.json")
+        try:
+            with open(details_path, "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {details_path}: {e}", file=sys.stderr)
+            details_path = None
+        print(json.dumps(compact_line(line, details_path), separators=(",", ":")), flush=True)
     if dist.is_initialized():
         dist.barrier(group=side)
         dist.destroy_process_group()

@@ -4,7 +4,7 @@
 # usage (through gpurun, from the repo root): tools/round_run.sh <tag> [steps...]
 #   steps: tests profiles soaks clock mixed
 set -u
-TAG=${1:-r05}; shift || true
+TAG=${1:-r06}; shift || true
 STEPS=${*:-tests profiles soaks clock mixed}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_final
