@@ -263,6 +263,7 @@ F64_ISSUE_TWAVEINSTR_S = 0.56     # measured f64 VALU issue rate, T wave-instr/s
 F64_ISSUE_NOMINAL_TWAVEINSTR_S = 256 * 4 * 2.4e9 / 4 / 1e12   # 0.6144: the same pipe at the specified 2.4 GHz (78.6 TF as FMA;
                                   # /opt/skills/guides/MI355X_MICROARCH.md chip table: 256 CU x 4 SIMD, 2 400 MHz)
 LINE_BYTES_MAX = 1700             # the printed line: the driver keeps the last 2 000 bytes of stdout + stderr
+LINE_BYTES_MAX_LAUNCHED = 1450    # N > 1: torch.distributed.run adds ~420 bytes of its own to stderr (OMP_NUM_THREADS note)
 # f64 wave-instructions per window the arithmetic needs, by FIR mode: mode 0 the
 # reference's unfused FIR (25 ops/output) and two-op normalisation; 1: 17 ops/output; 2: no normalisation
 F64_FLOOR_INSTR_PER_WINDOW = {0: 289, 1: 255, 2: 247}
@@ -450,7 +451,7 @@ def compact_line(d, details_path=None, limit=LINE_BYTES_MAX):
     line["roofline"] = None if not rf else {
         "bound": rf.get("bound"), "kernel": rf.get("kernel"), "achieved": _sig(rf.get("achieved")), "peak": rf.get("peak"),
         "unit": rf.get("unit"), "frac": _sig(rf.get("frac")), "traffic": _sig(rf.get("traffic"), 6),
-        "traffic_src": ("live_pmc" if "collected in this run" in str((rf.get("traffic_source") or {}).get("what", ""))
+        "traffic_src": ("live_pmc" if str((rf.get("traffic_source") or {}).get("what", "")).startswith("collected in this run")
                         else ((rf.get("traffic_source") or {}).get("file") if rf.get("traffic") else None)),
         "ms_avg_launch": _sig(rf.get("ms_avg_launch")), "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
         "frac_of_f64_floor": _sig(rf.get("frac_of_f64_floor"), 4),
@@ -469,6 +470,8 @@ def compact_line(d, details_path=None, limit=LINE_BYTES_MAX):
         ("distance_matrix_10k_s", _sig(d.get("distance_matrix_10k_s"), 4)),
         ("rehearsal", True if d.get("rehearsal") else None),
         ("details", os.path.basename(details_path) if details_path else None),
+        ("collective", (d.get("collective") or {}).get("backend")),
+        ("per_rank_ms", [_sig(x, 5) for x in (d.get("per_rank") or {}).get("ms_per_step", [])] if (d.get("n_gpus") or 1) > 1 else None),
         ("other_configs", None if not oc else ({"error": str(oc["error"])[:80]} if "error" in oc else {
             "configs1_ms": _sig((oc.get("configs1") or {}).get("ms_per_batch"), 4),
             "configs1_songs_per_s": _sig((oc.get("configs1") or {}).get("songs_per_s"), 4),
@@ -477,8 +480,6 @@ def compact_line(d, details_path=None, limit=LINE_BYTES_MAX):
             "ok": bool((oc.get("configs1") or {}).get("results_ok") and (oc.get("configs4_mixed") or {}).get("results_ok"))})),
         ("device_state", {"sclk_mhz": (ds.get("sclk_mhz") or {}).get("mean"), "power_w": (ds.get("power_w") or {}).get("mean"),
                           "power_cap_w": ds.get("power_cap_w"), "joules_per_song": _sig(ds.get("joules_per_song"), 3)}),
-        ("per_rank_ms", [_sig(x, 5) for x in (d.get("per_rank") or {}).get("ms_per_step", [])] if (d.get("n_gpus") or 1) > 1 else None),
-        ("collective", (d.get("collective") or {}).get("backend")),
         ("strict_1e-4_rel_failures", sum(strict.values()) if strict else None),
         ("freq_scan", None if not fs else {"ms": _sig(fs.get("ms_avg_launch"), 4), "frac_hbm": _sig(fs.get("frac"), 3)}),
         ("distance_matrix_10k_frac_hbm", _sig(d.get("distance_matrix_10k_frac_hbm"), 3)),
@@ -491,6 +492,46 @@ def compact_line(d, details_path=None, limit=LINE_BYTES_MAX):
         if len(json.dumps(out, separators=(",", ":"))) <= limit or not optional:
             return out
         optional.pop()
+
+
+class QuietFds:
+    """While a rank runs, its fd 1 and fd 2 go to a log file: RCCL prints a version banner and gloo its connection
+    notes on stdout, libdrm a complaint about amdgpu.ids on stderr per process — and the driver keeps only the last
+    2 000 bytes of stdout + stderr, which have to hold the JSON line.  `out` is the real stdout (the line goes there and
+    nothing else does); when the run fails the log's tail and the error are replayed on the real stderr."""
+
+    def __init__(self, tag):
+        import tempfile
+        sys.stdout.flush()
+        sys.stderr.flush()
+        self.path = os.path.join(tempfile.gettempdir(), f"bench_py_{tag}_{os.getpid()}.log")
+        self.out = os.fdopen(os.dup(1), "w")
+        self.err_fd = os.dup(2)
+        log = os.open(self.path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.dup2(log, 1)
+        os.dup2(log, 2)
+        os.close(log)
+
+    def replay(self, keep=6000):
+        """Back to the real stderr, with what the log holds."""
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os.dup2(self.err_fd, 2)
+        os.dup2(self.err_fd, 1)
+        try:
+            with open(self.path, errors="replace") as f:
+                txt = f.read()
+            if txt:
+                sys.stderr.write(f"---- {self.path} (last {keep} bytes) ----\n{txt[-keep:]}\n")
+        except OSError:
+            pass
+        sys.stderr.flush()
+
+    def done(self):
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass
 
 
 def _free_port():
@@ -602,6 +643,9 @@ def main():
                          "only, ~20 s): take the committed profile's figure")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the untimed-for-value legs on BASELINE configs[1] and configs[4] (profiling runs)")
+    ap.add_argument("--verbose", action="store_true",
+                    help="leave stdout / stderr of the rank alone (default: library chatter goes to a log file in the temp "
+                         "directory, replayed on failure, so that stdout is the JSON line and stderr stays short)")
     ap.add_argument("--details-out", default="",
                     help="where the full record goes (verification per song, per-kernel times, CPU ladder, traffic by "
                          "kernel ...; default: bench_details.json next to this script); stdout carries the compact line only")
@@ -627,6 +671,21 @@ def main():
         raise SystemExit(self_launch(args, sys.argv[1:]))
     if args.plumbing_only:
         raise SystemExit(plumbing_only(args))
+    if args.verbose:
+        return run_rank(args, under_launcher, sys.stdout)
+    quiet = QuietFds(f"rank{os.environ.get('RANK', '0')}")
+    try:
+        run_rank(args, under_launcher, quiet.out)
+    except BaseException as e:
+        if not (isinstance(e, SystemExit) and e.code in (0, None)):
+            quiet.replay()
+        raise
+    quiet.done()
+
+
+def run_rank(args, under_launcher, out):
+    """One rank of the job (the only one at N = 1): everything it or a library prints goes wherever fd 1 / fd 2 point;
+    the JSON line goes to `out`."""
 
     import numpy as np
     import torch
@@ -1054,7 +1113,8 @@ def main():
         except OSError as e:
             print(f"bench.py: could not write {details_path}: {e}", file=sys.stderr)
             details_path = None
-        print(json.dumps(compact_line(line, details_path), separators=(",", ":")), flush=True)
+        limit = LINE_BYTES_MAX if world == 1 else LINE_BYTES_MAX_LAUNCHED
+        print(json.dumps(compact_line(line, details_path, limit), separators=(",", ":")), file=out, flush=True)
     if dist.is_initialized():
         dist.barrier(group=side)
         dist.destroy_process_group()
