@@ -1111,9 +1111,12 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
   /* mode 2 filters the integers k = s - mean themselves (the taps carry the division) */
   auto nrm = [&](int k) -> double { return FIR_MODE == 2 ? (double)k : bl_norm(k, rcp, rcp_lo); };
   const int r0 = run_begin(u0 + wave), r1 = run_begin(u0 + wave + 1);
-  /* pass-1 twiddles kept in registers, the rest read from LDS in the round: modes 0 / 1 have room for 12
-   * (220 VGPRs); mode 2 needs fewer registers for the FIR and takes all 15 (213 VGPRs, no spill; 1 % faster) */
-  constexpr int EV3_W1_REGS = FIR_MODE == 2 ? 16 : 13;
+  /* all 15 pass-1 twiddles of the lane live in registers for the whole run: 194 / 192 / 213 VGPRs in FIR modes
+   * 0 / 1 / 2, no spill.  (Until round 6 modes 0 / 1 kept 12 and read three per round from LDS — a relic of a 220-VGPR
+   * build; the 185-VGPR one had the room: 44.15 -> 41.99 ms per 1 024 S180 songs in mode 0, identical records.  The
+   * eight split twiddles W512^(l + 16 k0) as well — 218 VGPRs — made mode 0 10 % SLOWER and mode 2 no faster:
+   * profiles/EXPERIMENTS.md.) */
+  constexpr int EV3_W1_REGS = 16;
   c2d w1r[EV3_W1_REGS];
 #pragma unroll
   for (int k1 = 1; k1 < EV3_W1_REGS; ++k1) {
