@@ -63,12 +63,15 @@ void orc_cosine_matrix(const float *vecs, int n, float *out);
 /* FFTs (orc_fft.c) */
 void orc_rdft512_f32(float *x);                 /* in-place, FFmpeg packed layout */
 void orc_r2c512_f64(const double *in, double *re, double *im); /* k = 0..256 */
-/* which implementation the two above run (orc_fft_alt.c): 0 the packed radix-2 of orc_fft.c (default; every
- * committed golden), 1 recursive radix-4 on the unpacked complex input, 2 the defining sum in extended precision */
+/* which implementation the two above run: 0 the defaults — f64: the packed radix-2 of orc_fft.c; f32: libavcodec's
+ * split-radix operation order, orc_fft_lavc.c (every committed golden since round 6) —, 1 recursive radix-4 on the
+ * unpacked complex input, 2 the defining sum in extended precision (orc_fft_alt.c), 3 = the f32 default by name,
+ * 4 the f32 packed radix-2 of orc_fft.c (the f32 default until round 6); 3 and 4 leave the f64 transform at 0's */
 void orc_set_fft_variant(int v);
 int orc_fft_variant(void);
 void orc_alt_r2c512_f64(int variant, const double *in, double *re, double *im);
 void orc_alt_rdft512_f32(int variant, float *x);
+void orc_lavc_rdft512_f32(float *x);            /* orc_fft_lavc.c: libavcodec fft_template.c / rdft.c operation order */
 
 /* integer-only synthetic PCM (orc_synth.c); identical bytes on every machine */
 int16_t orc_synth_sample(uint32_t seed, uint32_t rate, uint32_t channels, uint32_t i);

@@ -13,6 +13,9 @@
  * in the same precision as the library being replaced (f32 resp. f64).
  * Parity is anchored on the reference's goldens (tests/test_analyze.c:30-35),
  * which these reproduce to within the test's own 1e-5.
+ * Since round 6 the f32 transform the oracle RUNS is orc_fft_lavc.c (libavcodec's
+ * own operation order: every golden value to the last printed digit); the f32
+ * radix-2 here stays as variant 4, the f64 one is the default f64 transform.
  */
 #include <math.h>
 #include "bliss_oracle.h"
@@ -81,7 +84,12 @@ DEFINE_CFFT(cfft256_f64, double, g_cw, g_sw)
 /* f32, in place, FFmpeg RDFT packed output:
  * x[0]=Re X0, x[1]=Re X256, x[2k]=Re Xk, x[2k+1]=Im Xk (k=1..255). */
 void orc_rdft512_f32(float *x) {
-  if (orc_fft_variant() != 0) { orc_alt_rdft512_f32(orc_fft_variant(), x); return; } /* cross-checks: orc_fft_alt.c */
+  /* default (0) and 3: libavcodec's operation order (orc_fft_lavc.c) — the one f32 DFT under which the oracle prints
+   * all ten golden values of ref tests/test_analyze.c:30-35,62-68 to the last digit; 1, 2: the cross-checks of
+   * orc_fft_alt.c; 4: the packed radix-2 below, the default until round 6 */
+  const int variant = orc_fft_variant();
+  if (variant == 0 || variant == 3) { orc_lavc_rdft512_f32(x); return; }
+  if (variant == 1 || variant == 2) { orc_alt_rdft512_f32(variant, x); return; }
   float zr[HALF], zi[HALF];
   init_tables();
   for (int m = 0; m < HALF; ++m) { zr[m] = x[2 * m]; zi[m] = x[2 * m + 1]; }
@@ -100,7 +108,7 @@ void orc_rdft512_f32(float *x) {
 
 /* f64, out of place: re[k], im[k] for k = 0..256 (FFTW r2c layout). */
 void orc_r2c512_f64(const double *in, double *re, double *im) {
-  if (orc_fft_variant() != 0) { orc_alt_r2c512_f64(orc_fft_variant(), in, re, im); return; }
+  if (orc_fft_variant() == 1 || orc_fft_variant() == 2) { orc_alt_r2c512_f64(orc_fft_variant(), in, re, im); return; }
   double zr[HALF], zi[HALF];
   init_tables();
   for (int m = 0; m < HALF; ++m) { zr[m] = in[2 * m]; zi[m] = in[2 * m + 1]; }

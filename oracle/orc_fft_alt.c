@@ -11,7 +11,8 @@
  *              double products, sums and twiddles (cosl / sinl), rounded to double once; the f32 transform in
  *              double, rounded to float once — what every FFT of that precision approximates.
  * orc_set_fft_variant() selects what orc_rdft512_f32 / orc_r2c512_f64 (and therefore orc_frequency / orc_envelope)
- * run; 0, the default, is the packed radix-2 of orc_fft.c every committed golden was made with.
+ * run; 0, the default: f64 the packed radix-2 of orc_fft.c, f32 libavcodec's operation order (orc_fft_lavc.c, also
+ * variant 3); 4: the f32 packed radix-2 of orc_fft.c, the default until round 6.
  * Used by tests/test_fft_independence.py and tools/fft_independence.py only.
  */
 #include <math.h>
@@ -21,7 +22,7 @@
 #define N 512
 
 static int g_variant = 0;
-void orc_set_fft_variant(int v) { g_variant = (v >= 0 && v <= 2) ? v : 0; }
+void orc_set_fft_variant(int v) { g_variant = (v >= 0 && v <= 4) ? v : 0; }
 int orc_fft_variant(void) { return g_variant; }
 
 static int g_init = 0;

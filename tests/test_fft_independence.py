@@ -2,9 +2,10 @@
 
 The reference computes its window energies with FFTW3 (f64, ref src/tempo_atk_sort.c:141-149) and its frequency
 rating with libavcodec's RDFT (f32, ref src/frequency_sort.c:83-93); neither library exists in this image, and the
-oracle restates both as a packed radix-2 (oracle/orc_fft.c).  oracle/orc_fft_alt.c holds two more implementations —
-a recursive radix-4 on the unpacked complex input and the defining sum in extended precision — and these tests run
-the reference's recording and the committed synthetic cases under all of them:
+oracle restates the f64 one as a packed radix-2 (oracle/orc_fft.c) and — since round 6 — the f32 one in libavcodec's own
+operation order (oracle/orc_fft_lavc.c).  oracle/orc_fft_alt.c holds two more implementations of both — a recursive
+radix-4 on the unpacked complex input and the defining sum in extended precision — and these tests run the
+reference's recording and the committed synthetic cases under all of them:
   * every f32-rounded window energy (ref :142-149), every integer of the analysis and tempo / attack are identical
     bit for bit whichever f64 DFT is used: "bit-identical to the oracle" does not mean "to the oracle's radix-2";
   * `frequency` moves by a few 1e-6 absolute with the f32 DFT — inside the reference's own 1e-5 absolute tolerance
@@ -70,7 +71,7 @@ def test_frequency_spread_over_f32_dfts_is_inside_the_reference_tolerance(lib, o
         if pcm.size > 3_000_000:
             continue
         f = []
-        for v in (0, 1, 2):
+        for v in (0, 1, 2, 4):   # libavcodec's order (the default), radix-4, the defining sum, packed radix-2
             oracle.set_fft_variant(v)
             try:
                 f.append(oracle.frequency(pcm, ch))
@@ -99,13 +100,34 @@ def test_alternative_dfts_agree_with_numpy(oracle):
         assert np.allclose(re + 1j * im, want, rtol=0, atol=2e-13), v
     xf = x.astype(np.float32)
     fp = C.POINTER(C.c_float)
-    oracle.lib.orc_alt_rdft512_f32.argtypes = [C.c_int, fp]
     oracle.lib.orc_rdft512_f32.argtypes = [fp]
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3, 4):   # all four f32 transforms through the dispatcher (0 and 3 are the same one)
         buf = xf.copy()
-        if v == 0:
+        oracle.set_fft_variant(v)
+        try:
             oracle.lib.orc_rdft512_f32(buf.ctypes.data_as(fp))
-        else:
-            oracle.lib.orc_alt_rdft512_f32(v, buf.ctypes.data_as(fp))
+        finally:
+            oracle.set_fft_variant(0)
         got = np.concatenate(([buf[0]], buf[2::2] + 1j * buf[3::2], [buf[1]]))
         assert np.allclose(got, np.fft.rfft(xf.astype(np.float64)), rtol=0, atol=2e-4), v
+
+
+def test_only_libavcodecs_order_prints_the_reference_goldens(lib, oracle):
+    """Which f32 DFT the reference ran is visible in its own test (ref tests/test_analyze.c:34): `frequency` of
+    audio/song.flac is -10.136086 there.  Of the four f32 transforms in oracle/ only libavcodec's split-radix
+    operation order (orc_fft_lavc.c: variants 0 = default and 3) gives a float that prints as that literal; the packed
+    radix-2 (the oracle's default until round 6) and the radix-4 land 2.4e-6 below it, the defining sum 3.4e-6
+    above.  The same holds for `force` (:30) and for both values of the second recording (tests/test_ingest.py)."""
+    name, pcm, ch, dur = next(iter(_cases(lib, oracle)))
+    assert name == "song.flac"
+    got = {}
+    for v in (0, 1, 2, 3, 4):
+        oracle.set_fft_variant(v)
+        try:
+            got[v] = float(np.float32(oracle.frequency(pcm, ch)))
+        finally:
+            oracle.set_fft_variant(0)
+    assert "%.6f" % got[0] == "%.6f" % got[3] == "-10.136086", got
+    for v in (1, 2, 4):
+        assert "%.6f" % got[v] != "-10.136086" and abs(got[v] + 10.136086) <= 1e-5, (v, got)
+    assert abs(got[0] + 10.136086) < 6e-7

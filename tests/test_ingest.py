@@ -136,6 +136,7 @@ def test_oracle_reproduces_reference_goldens_of_the_resampled_fixture(lib, oracl
                 attack=-15.561186)
     for k, want in gold.items():
         assert abs(r[k] - want) <= 1e-5, (k, r[k], want)
+        assert "%.6f" % float(np.float32(r[k])) == "%.6f" % want, (k, float(np.float32(r[k])), want)   # last printed digit
 
 
 def test_native_rate_opt_in(lib):
