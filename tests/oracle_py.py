@@ -28,7 +28,7 @@ FIELDS = [f[0] for f in OrcResult._fields_]
 def build_oracle():
     if not os.path.exists(LIB) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB)
-            for f in ("bliss_oracle.c", "orc_fft.c", "orc_fft_alt.c", "orc_synth.c", "bliss_oracle.h")):
+            for f in ("bliss_oracle.c", "orc_fft.c", "orc_fft_alt.c", "orc_fft_lavc.c", "orc_synth.c", "bliss_oracle.h")):
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
     return LIB
 
@@ -70,7 +70,8 @@ class Oracle:
         return a.ctypes.data_as(C.POINTER(C.c_int16))
 
     def set_fft_variant(self, v):
-        """0 packed radix-2 (default), 1 recursive radix-4 on the unpacked input, 2 the defining sum (orc_fft_alt.c)"""
+        """0 the defaults (f64: packed radix-2; f32: libavcodec's operation order, orc_fft_lavc.c), 1 recursive radix-4 on the
+        unpacked input, 2 the defining sum (orc_fft_alt.c), 3 = the f32 default by name, 4 the f32 packed radix-2"""
         self.lib.orc_set_fft_variant(v)
 
     def frequency(self, pcm, channels):

@@ -22,7 +22,7 @@ def test_fft_lane_code(tmp_path):
 
 
 def test_streaming_tail_matches_oracle(tmp_path):
-    orc = [os.path.join(ROOT, "oracle", f) for f in ("bliss_oracle.c", "orc_fft.c", "orc_fft_alt.c", "orc_synth.c")]
+    orc = [os.path.join(ROOT, "oracle", f) for f in ("bliss_oracle.c", "orc_fft.c", "orc_fft_alt.c", "orc_fft_lavc.c", "orc_synth.c")]
     _run(tmp_path, "test_tail_host.cpp", ["-x", "c"] + orc)
 
 
