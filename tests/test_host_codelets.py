@@ -21,6 +21,12 @@ def test_fft_lane_code(tmp_path):
     _run(tmp_path, "test_fft_host.cpp", [])
 
 
+def test_lavc_order_lane_code_is_bit_identical_to_the_oracle(tmp_path):
+    """bl_fft_lavc.h (the frequency kernel's f32 DFT: libavcodec's operation order on 16 lanes x 16 registers) against
+    oracle/orc_fft_lavc.c: 127 500 power values of 500 frames, bit for bit."""
+    _run(tmp_path, "test_fft_lavc_host.cpp", ["-x", "c", os.path.join(ROOT, "oracle", "orc_fft_lavc.c")])
+
+
 def test_streaming_tail_matches_oracle(tmp_path):
     orc = [os.path.join(ROOT, "oracle", f) for f in ("bliss_oracle.c", "orc_fft.c", "orc_fft_alt.c", "orc_fft_lavc.c", "orc_synth.c")]
     _run(tmp_path, "test_tail_host.cpp", ["-x", "c"] + orc)
