@@ -75,9 +75,8 @@ enum {
 };
 /* leaf constants: lv_leafc[0] = sqrthalf, [1] = cos_16[1], [2] = cos_16[3] */
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 #include <math.h>
-/* The tables, exactly as libavcodec builds them: cos_m[i] = (float)cos(i * 2 pi / m) for i <= m / 4, mirrored
+/* Host only.  The tables, exactly as libavcodec builds them: cos_m[i] = (float)cos(i * 2 pi / m) for i <= m / 4, mirrored
  * cos_m[m / 2 - i] = cos_m[i]; a pass reads (cos_n[k], cos_n[n / 4 - k]), the post-pass (cos_512[i],
  * cos_512[128 + i]).  k = 0 is TRANSFORM_ZERO: (1, 0). */
 static inline float lv_cos_tab(int m, int i) {
@@ -108,7 +107,6 @@ static inline void lv_fill_tables(float (*tw)[2] /* [LV_TW_SLOTS * 16] */, float
   leafc[2] = lv_cos_tab(16, 3);
   leafc[3] = 0.0f;
 }
-#endif
 
 /* ---- butterflies (fft_template.c: BF, BUTTERFLIES, TRANSFORM) --------------- */
 

@@ -35,6 +35,7 @@
 #include <string.h>
 
 #include "bl_launch.h"
+#include "bl_fft_lavc.h"
 #include "bl_cos.h"
 #include "bl_sqrt.h"
 #include "bl_tail.h"
@@ -739,14 +740,279 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) gh[i] = lh[i]; /* the workgroup owns the song: plain stores */
 }
 
+/*
+ * The same pass with the transform in libavcodec's operation order (bl_fft_lavc.h): what the reference's
+ * av_rdft_calc computes node for node, so that the power values — and with them `frequency` — are the oracle's bit
+ * for bit (the oracle under that order prints the reference's golden values to the last digit).
+ * Differences to freq_frames_body: the input is gathered in split-radix order (lane L register r = element
+ * (lv_base(L) + K[r]) mod 256 of the frame: immediate offsets from one per-lane base, every 8-byte element still
+ * loaded exactly once, 16 lanes per load inside a 16-element neighbourhood), the leaves run in that layout, ONE
+ * transpose, then pass(32) with its products exchanged between lanes l and l ^ 8 by DPP, pass(64 .. 256) in
+ * registers, rdft.c's post-pass with the partner by DPP as before, and re * re + im * im unfused.  Everything around
+ * the transform — prefetch, statistics, staging, the baton — is freq_frames_body's.
+ */
+template <bool STEREO, int WAVES, bool SCAN>
+__device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm, const bl_dsong &sg,
+                                                 const bl_tables &tb, float *spectrum, bl_dstats *st,
+                                                 unsigned *gh) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int FPI = 8 * WAVES; /* frames per workgroup iteration */
+  c2p *xch = reinterpret_cast<c2p *>(smem); /* 4 WAVES x 272 */
+  c2f *lvtw = reinterpret_cast<c2f *>(smem + BL_FREQ_XCH_BYTES(WAVES)); /* [LV_TW_SLOTS][16 lanes] */
+  float *hann = reinterpret_cast<float *>(smem + BL_FREQ_XCH_BYTES(WAVES) + 2 * 256 * 8);
+  float *accv = reinterpret_cast<float *>(smem + BL_FREQ_ACC_OFF(WAVES)); /* ps[0..255] so far */
+  unsigned *lh = reinterpret_cast<unsigned *>(smem + BL_FREQ_HIST_OFF(WAVES)); /* SCAN: the histogram */
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF(WAVES) + 256 * 4);
+  const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, gl = g & 3;
+  const int16_t *p = pcm + sg.pcm_off;
+  if (WAVES == 4 || tid < 256) {
+    lvtw[tid] = tb.lv_tw[tid];
+    hann[tid] = tb.hann[tid];
+    hann[tid + 256] = tb.hann[tid + 256];
+    accv[tid] = 0.f;
+  }
+  if (SCAN)
+    for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) lh[i] = 0;
+  if (tid == 0) relay[0] = 0;
+  __syncthreads();
+  unsigned lds_hist = (unsigned)(size_t)(bl_lds_u32 *)lh;
+  asm volatile("" : "+v"(lds_hist)); /* lives in a VGPR: as a scalar it is copied in front of every use */
+  long long sum = 0;
+  unsigned long long sq = 0;
+
+  /* this lane's place in the split-radix order (bl_fft_lavc.h): T8 lanes 1, 5, 7, 9, 13; base element lv_base(l),
+   * from which the lanes with base >= 251 wrap for every register but the first */
+  const bool t16 = ((0x22A2u >> l) & 1u) == 0u;
+  const unsigned long long bases = l < 8 ? 0x06FE0A02FC040800ull : 0xFB0307FFFD050901ull; /* lv_base(), a byte per lane */
+  const int base0 = (int)((bases >> (8 * (l & 7))) & 0xFFu);
+  const int basep = base0 >= 251 ? base0 - 256 : base0;
+  const bool lo8 = l < 8;
+  /* gather order of the registers: lv_k_lo | lv_k_hi(true, .) */
+  constexpr int KG[16] = {0, 128, 64, 192, 32, 160, 224, 96, 16, 144, 80, 208, 240, 112, 48, 176};
+  static_assert(lv_gather_index(3, 1) == ((252 + 128) & 255) && lv_gather_index(12, 0) == 255 && lv_base(15) == 251, "lv tables");
+
+  c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* the transpose buffer of this 16-lane group */
+  float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [8][BL_FREQ_SROW] */
+  uint2 pa[16], pb[16];
+  constexpr bool stereo = STEREO;
+  auto fetch = [&](int f_, int part) {
+    const int fa = min(f_, sg.n_frames - 1), fb = min(f_ + 1, sg.n_frames - 1);
+    if (stereo) {
+      const uint2 *qa = reinterpret_cast<const uint2 *>(p + (size_t)fa * 1024) + basep;
+      const uint2 *qb = reinterpret_cast<const uint2 *>(p + (size_t)fb * 1024) + basep;
+#pragma unroll
+      for (int r = 4 * part; r < 4 * part + 4; ++r) {
+        const int e = r == 0 ? base0 - basep : KG[r];
+        pa[r] = qa[e]; pb[r] = qb[e];
+      }
+    } else {
+      const unsigned *qa = reinterpret_cast<const unsigned *>(p + (size_t)fa * 512) + basep;
+      const unsigned *qb = reinterpret_cast<const unsigned *>(p + (size_t)fb * 512) + basep;
+#pragma unroll
+      for (int r = 4 * part; r < 4 * part + 4; ++r) {
+        const int e = r == 0 ? base0 - basep : KG[r];
+        pa[r] = make_uint2(qa[e], 0u);
+        pb[r] = make_uint2(qb[e], 0u);
+      }
+    }
+  };
+  auto mono2 = [&](const uint2 wa, const uint2 wb, bl_f2 &s0, bl_f2 &s1) { /* see freq_frames_body */
+    const int a0 = (int)(short)(wa.x & 0xFFFFu), a1 = (int)(short)(wa.x >> 16);
+    const int b0 = (int)(short)(wb.x & 0xFFFFu), b1 = (int)(short)(wb.x >> 16);
+    if (stereo) {
+      const int a2 = (int)(short)(wa.y & 0xFFFFu), a3 = (int)(short)(wa.y >> 16);
+      const int b2 = (int)(short)(wb.y & 0xFFFFu), b3 = (int)(short)(wb.y >> 16);
+      const bl_f2 h0 = (bl_f2){(float)(a0 + a1), (float)(b0 + b1)} * 0.5f;
+      const bl_f2 h1 = (bl_f2){(float)(a2 + a3), (float)(b2 + b3)} * 0.5f;
+      s0 = (bl_f2){__builtin_truncf(h0.x), __builtin_truncf(h0.y)};
+      s1 = (bl_f2){__builtin_truncf(h1.x), __builtin_truncf(h1.y)};
+    } else {
+      s0 = (bl_f2){(float)a0, (float)b0};
+      s1 = (bl_f2){(float)a1, (float)b1};
+    }
+  };
+  auto bc = [](float w) { return (bl_f2){w, w}; };
+  /* the lane's twiddles of the in-register passes stay in registers for the whole song; pass(32)'s carries the sign
+   * of its half of the pair (lv_pass32_mul) */
+  const c2f w32 = lvtw[LV_TW_P32 * 16 + l], w64 = lvtw[LV_TW_P64 * 16 + l];
+  const float ws32 = lo8 ? -w32.im : w32.im;
+  c2f w128[2], w256[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) w128[q] = lvtw[(LV_TW_P128 + q) * 16 + l];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w256[q] = lvtw[(LV_TW_P256 + q) * 16 + l];
+  const bl_f2 SH = bc(tb.lv_leafc[0]), C1 = bc(tb.lv_leafc[1]), C3 = bc(tb.lv_leafc[2]);
+  const bl_f2 *hann2 = reinterpret_cast<const bl_f2 *>(hann) + basep;
+  const int n_iter = (sg.n_frames + FPI - 1) / FPI;
+#pragma unroll
+  for (int part = 0; part < 4; ++part) fetch(8 * wave + 2 * gl, part);
+  for (int it = 0; it < n_iter; ++it) {
+    const int f = it * FPI + 8 * wave + 2 * gl;
+    if (SCAN) __builtin_amdgcn_s_setprio(3);
+    bl_f2 re[16], im[16];
+    int s32 = 0;
+    auto word = [&](unsigned w) { scan_word(w, s32, sq, lds_hist, true); };
+    const bool full = it + 1 < n_iter; /* wave-uniform */
+    const bool va = f < sg.n_frames, vb = f + 1 < sg.n_frames;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bl_f2 xr, xi;
+      if (SCAN) {
+        if (full) {
+          word(pa[r].x); word(pb[r].x);
+          if (stereo) { word(pa[r].y); word(pb[r].y); }
+        } else {
+          if (va) { word(pa[r].x); if (stereo) word(pa[r].y); }
+          if (vb) { word(pb[r].x); if (stereo) word(pb[r].y); }
+        }
+      }
+      mono2(pa[r], pb[r], xr, xi);
+      const bl_f2 h = hann2[r == 0 ? base0 - basep : KG[r]]; /* hann[2 m], hann[2 m + 1] of this register's element m */
+      re[r] = xr * (bl_f2){h.x, h.x};
+      im[r] = xi * (bl_f2){h.y, h.y};
+    }
+    if (SCAN) sum += s32;
+    fetch(f + FPI, 0);
+    if (SCAN) __builtin_amdgcn_s_setprio(2);
+    lv_leaves<bl_f2>(t16, re, im, SH, C1, C3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      c2p v; v.re = re[r]; v.im = im[r];
+      gx[r * 17 + l] = v;
+    }
+    bl_wave_sync();
+    fetch(f + FPI, 1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const c2p v = gx[l * 17 + j];
+      re[j] = v.re; im[j] = v.im;
+    }
+    bl_wave_sync();
+    fetch(f + FPI, 2);
+    if (SCAN) __builtin_amdgcn_s_setprio(0);
+    { /* pass(32) @ 0, 64, 96, 128, 192: registers (R, R + 1), lanes l and l ^ 8 */
+      auto sel = [&](bl_f2 a, bl_f2 b) { return lo8 ? a : b; };
+      constexpr int R32[5] = {0, 4, 6, 8, 12};
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int R = R32[b];
+        bl_f2 tA, tB;
+        lv_pass32_mul<bl_f2>(re[R + 1], im[R + 1], bc(w32.re), bc(ws32), tA, tB);
+        const bl_f2 pA = bl_dpp_f2<0x128>(tA), pB = bl_dpp_f2<0x128>(tB); /* row_ror:8 = lane ^ 8 */
+        lv_pass32_fin<bl_f2>(re[R], im[R], re[R + 1], im[R + 1], tA, tB, pA, pB, sel);
+      }
+    }
+    lv_pass_inlane<bl_f2, 0, 1>(re, im, bc(w64.re), bc(w64.im));
+    lv_pass_inlane<bl_f2, 8, 1>(re, im, bc(w64.re), bc(w64.im));
+    lv_pass_inlane<bl_f2, 12, 1>(re, im, bc(w64.re), bc(w64.im));
+    lv_pass_inlane<bl_f2, 0, 2>(re, im, bc(w128[0].re), bc(w128[0].im));
+    lv_pass_inlane<bl_f2, 1, 2>(re, im, bc(w128[1].re), bc(w128[1].im));
+    lv_pass_inlane<bl_f2, 0, 4>(re, im, bc(w256[0].re), bc(w256[0].im));
+    lv_pass_inlane<bl_f2, 1, 4>(re, im, bc(w256[1].re), bc(w256[1].im));
+    lv_pass_inlane<bl_f2, 2, 4>(re, im, bc(w256[2].re), bc(w256[2].im));
+    lv_pass_inlane<bl_f2, 3, 4>(re, im, bc(w256[3].re), bc(w256[3].im));
+    fetch(f + FPI, 3);
+    /* rdft.c's post-pass: the partner of i = l + 16 j is Z[256 - i], register 15 - j of lane 16 - l (row mirror +
+     * shift by one, as in freq_frames_body); lane 0 is its own partner and takes its register 16 - j */
+    bl_f2 own[8], mir[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bl_f2 zr = j ? re[16 - j] : re[0];
+      const bl_f2 zi = j ? im[16 - j] : im[0];
+      const bl_f2 pr = bl_dpp_f2_old<0x111>(zr, bl_dpp_f2<0x140>(re[15 - j]));
+      const bl_f2 pi = bl_dpp_f2_old<0x111>(zi, bl_dpp_f2<0x140>(im[15 - j]));
+      const c2f w = lvtw[(LV_TW_POST + j) * 16 + l];
+      lv_post_power<bl_f2>(re[j], im[j], pr, pi, bc(w.re), bc(w.im), bc(0.5f), own[j], mir[j]);
+    }
+    const bl_f2 mid = lv_mid_power<bl_f2>(re[8], im[8]);
+    /* ref :88-93: re*re + im*im of bin d, for d = 1..255 (lane 0's own[0] / mir[0] are bins 0 / 256: never read) */
+    float *sa = stage + (2 * gl) * BL_FREQ_SROW, *sb = sa + BL_FREQ_SROW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sa[l + 16 * k] = own[k].x; sb[l + 16 * k] = own[k].y;
+      sa[256 - l - 16 * k] = mir[k].x; sb[256 - l - 16 * k] = mir[k].y;
+    }
+    if (l == 0) { sa[128] = mid.x; sb[128] = mid.y; }
+    bl_wave_sync();
+    const int turn = WAVES * it + wave;
+    const int n_live = sg.n_frames - (it * FPI + 8 * wave);
+    float sv[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int fr = 0; fr < 8; ++fr) sv[q][fr] = stage[fr * BL_FREQ_SROW + lane + 64 * q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    while (__builtin_amdgcn_readfirstlane(relay[0]) < turn) __builtin_amdgcn_s_sleep(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = accv[lane + 64 * q];
+    if (n_live >= 8) {
+#pragma unroll
+      for (int fr = 0; fr < 8; ++fr)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[q] += sv[q][fr];
+          asm volatile("" : "+v"(acc[q]));
+        }
+    } else {
+#pragma unroll
+      for (int fr = 0; fr < 8; ++fr)
+        if (fr < n_live) { /* wave-uniform */
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += sv[q][fr];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accv[lane + 64 * q] = acc[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bl_wave_sync();
+    if (lane == 0) relay[0] = turn + 1;
+  }
+  if (SCAN) {
+    for (int i = sg.n_frames * 512 * sg.channels + tid; i < sg.n; i += 64 * WAVES) {
+      const int sv = (int)p[i];
+      sum += sv;
+      sq += (unsigned)(sv * sv);
+      const unsigned b = (unsigned)(sv + BL_HIST_BINS / 2);
+      if (b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sum += __shfl_down(sum, off);
+      sq += __shfl_down(sq, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&st->sum, (unsigned long long)sum);
+      atomicAdd(&st->sumsq, sq);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (WAVES == 4 || tid < 256) spectrum[(size_t)blockIdx.x * 256 + tid] = accv[tid];
+  if (SCAN)
+    for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) gh[i] = lh[i];
+}
+
+#ifndef BL_FREQ_LAVC
+#define BL_FREQ_LAVC 1 /* 0: the fused radix-16 transform of rounds 1-5 (freq_frames_body), for A/B measurements */
+#endif
+#if BL_FREQ_LAVC
+#define BL_FREQ_BODY freq_frames_lavc
+#else
+#define BL_FREQ_BODY freq_frames_body
+#endif
+
 /* one workgroup per song; the channel count is uniform per workgroup, so the branch costs one
  * scalar compare and each path keeps its compiled-in input side */
 __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restrict__ pcm,
                                                         const bl_dsong *__restrict__ songs,
                                                         bl_tables tb, float *spectrum) {
   const bl_dsong sg = songs[blockIdx.x];
-  if (sg.channels == 2) freq_frames_body<true, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
-  else freq_frames_body<false, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
+  if (sg.channels == 2) BL_FREQ_BODY<true, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
+  else BL_FREQ_BODY<false, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
 }
 
 /* k_freq_scan: k_freq_frames and k_pcm_scan in one pass over the PCM — one 512-thread workgroup per song and CU
@@ -758,8 +1024,8 @@ __global__ __launch_bounds__(64 * BL_FREQ_SCAN_WAVES) void k_freq_scan(const int
   const bl_dsong sg = songs[blockIdx.x];
   bl_dstats *st = stats + blockIdx.x;
   unsigned *gh = hist + (size_t)blockIdx.x * BL_HIST_BINS;
-  if (sg.channels == 2) freq_frames_body<true, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
-  else freq_frames_body<false, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
+  if (sg.channels == 2) BL_FREQ_BODY<true, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
+  else BL_FREQ_BODY<false, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
 }
 
 __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ spectrum,
@@ -1786,7 +2052,7 @@ __global__ __launch_bounds__(256) void k_extract_vecs(const bl_amd_song_result *
 /* ========================================================================= */
 /* launchers (declared in bl_launch.h)                                        */
 
-size_t blk_tables_bytes(void) { return 256 * 16 * 2 + 256 * 8 * 2 + 512 * 4; }
+size_t blk_tables_bytes(void) { return 256 * 16 * 2 + 256 * 8 * 2 + 512 * 4 + LV_TW_SLOTS * 16 * 8; }
 
 void blk_tables_fill_host(unsigned char *h) {
   /* twiddle / window tables, computed in double on the host */
@@ -1804,6 +2070,9 @@ void blk_tables_fill_host(unsigned char *h) {
   }
   /* ref frequency_sort.c:40-42 */
   for (int i = 0; i < 512; ++i) hann[i] = (float)(.5f * (1.0f - cos(2 * M_PI * i / (512 - 1))));
+  /* libavcodec's cosine tables, per lane and pass (bl_fft_lavc.h) */
+  float leafc[4];
+  lv_fill_tables(reinterpret_cast<float(*)[2]>(hann + 512), leafc);
 }
 
 bl_tables blk_tables_bind(const void *d_mem) {
@@ -1814,6 +2083,11 @@ bl_tables blk_tables_bind(const void *d_mem) {
   tb.tw256_f = reinterpret_cast<const c2f *>(tb.tw512_d + 256);
   tb.tw512_f = tb.tw256_f + 256;
   tb.hann = reinterpret_cast<const float *>(tb.tw512_f + 256);
+  tb.lv_tw = reinterpret_cast<const c2f *>(tb.hann + 512);
+  {
+    float tw[LV_TW_SLOTS * 16][2];
+    lv_fill_tables(tw, tb.lv_leafc);
+  }
   tb.log101 = log((double)(1 + 100.0f)); /* ref tempo_atk_sort.c:188, log(1 + mu) */
   return tb;
 }
