@@ -232,6 +232,7 @@ def verify_songs(res, picks, seed_first, seconds):
     """Untimed: re-synthesise `picks` of the resident batch on the host (same integer generator,
     seeds = global song index) and analyse them with the CPU oracle (orc_cli); integers must be
     identical, f32 features within 1e-4 relative (north_star).  Returns (ok, details)."""
+    import numpy as np
     from tests.oracle_py import build_oracle
     build_oracle()
     cli = os.path.join(ROOT, "oracle", "orc_cli")
@@ -252,8 +253,11 @@ def verify_songs(res, picks, seed_first, seconds):
             by_field[k] = rel
             if not rel <= 1e-4:
                 bad.append(k)
+        # all five f32 features bit-identical to the oracle's (orc_cli prints %.9g: a float survives the round trip)
+        bits = all(np.float32(g[k]).view(np.int32) == np.float32(ref[k]).view(np.int32) for k in by_field)
         details.append({"song": int(i), "beat": int(g["beat"]), "max_rel_err": worst, "rel_err_by_field": by_field,
-                        "value_by_field": {k: float(ref[k]) for k in by_field}, "mismatch": bad})
+                        "value_by_field": {k: float(ref[k]) for k in by_field}, "features_bit_identical": bool(bits),
+                        "mismatch": bad})
         ok = ok and not bad
     return ok, details
 
@@ -481,6 +485,7 @@ def compact_line(d, details_path=None, limit=LINE_BYTES_MAX):
         ("device_state", {"sclk_mhz": (ds.get("sclk_mhz") or {}).get("mean"), "power_w": (ds.get("power_w") or {}).get("mean"),
                           "power_cap_w": ds.get("power_cap_w"), "joules_per_song": _sig(ds.get("joules_per_song"), 3)}),
         ("strict_1e-4_rel_failures", sum(strict.values()) if strict else None),
+        ("bit_identical_songs", (d.get("verification") or {}).get("songs_with_all_features_bit_identical")),
         ("freq_scan", None if not fs else {"ms": _sig(fs.get("ms_avg_launch"), 4), "frac_hbm": _sig(fs.get("frac"), 3)}),
         ("distance_matrix_10k_frac_hbm", _sig(d.get("distance_matrix_10k_frac_hbm"), 3)),
         ("cosine_matrix_10k_s", _sig(d.get("cosine_matrix_10k_s"), 4)),
@@ -1064,6 +1069,8 @@ def run_rank(args, under_launcher, out):
                                         "ranks, the list below is rank 0's)",
                              "bar": "integers identical, f32 features <= 1e-4 relative (no absolute term)",
                              "n_failing_strict_1e-4_rel": strict,
+                             "songs_with_all_features_bit_identical": int(sum(1 for d in verify_details
+                                                                              if d.get("features_bit_identical"))),
                              "worst_rel_err_by_field": {k: max((d["rel_err_by_field"][k] for d in verify_details), default=None)
                                                         for k in ("tempo", "amplitude", "frequency", "attack", "force")},
                              "songs": verify_details},

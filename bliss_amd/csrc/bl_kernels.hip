@@ -92,8 +92,7 @@ __device__ __forceinline__ void scan_hist_word(unsigned w, unsigned lds_base) {
   bl_lds_u32 *h = (bl_lds_u32 *)(size_t)lds_base;
   if (b0 < BL_HIST_BINS) __hip_atomic_fetch_add(h + b0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (b1 < BL_HIST_BINS) __hip_atomic_fetch_add(h + b1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return;
-#endif
+#else
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   us2 v;
   __builtin_memcpy(&v, &w, 4);
@@ -109,6 +108,7 @@ __device__ __forceinline__ void scan_hist_word(unsigned w, unsigned lds_base) {
                "ds_add_u32 %0, %4\n\t"
                "ds_add_u32 %1, %4"
                : "=&v"(a0), "=&v"(a1) : "v"(b2), "v"(lds_base), "v"(one) : "memory");
+#endif
 }
 
 /* Everything the statistics take from one packed word of two samples: lo + hi into the 32-bit partial sum
@@ -435,12 +435,12 @@ __global__ __launch_bounds__(256) void k_amp_finish(const bl_dsong *__restrict__
 /*
  * Hann window + 512-point f32 real DFT + per-bin power, summed over the frames in the reference's order
  * (ref src/frequency_sort.c:67-94).  k_freq_frames is the frequency analysis alone (four waves per workgroup);
- * k_freq_scan is the same body with eight waves and the statistics pass riding along (see freq_frames_body) —
+ * k_freq_scan is the same body with eight waves and the statistics pass riding along (see freq_frames_lavc) —
  * what bl_analyze and the batch calls launch.
  *
  * One workgroup per song.  Every 16-lane group transforms TWO frames at once: all values are
- * 2-vectors (frame A in .x, frame B in .y), so the whole transform is v_pk_add / v_pk_mul /
- * v_pk_fma_f32 on register pairs with no shuffling between the halves — twice the f32 rate of
+ * 2-vectors (frame A in .x, frame B in .y), so the whole transform is v_pk_add / v_pk_mul_f32
+ * on register pairs with no shuffling between the halves — twice the f32 rate of
  * the scalar VALU for the same instruction count (the one-frame-per-group kernel spent 40 % of
  * its VALU stream on v_mov's that re-paired (re, im) for the packed instructions hipcc formed).
  * A wave covers 8 consecutive frames per iteration, the WAVES waves 8 * WAVES.
@@ -470,9 +470,19 @@ typedef bl_c2<bl_f2> c2p; /* a complex number per frame of the pair */
 #define BL_FREQ_SCAN_LDS_BYTES (BL_FREQ_HIST_OFF(BL_FREQ_SCAN_WAVES) + 4 * BL_HIST_BINS) /* k_freq_scan: 159.1 KB */
 /* row stride of the power staging: 2 rows = 16 banks (mod 32) apart, so the two 16-lane groups
  * that share a 32-lane store group land on disjoint banks */
-static_assert(BL_FREQ_HIST_OFF(BL_FREQ_SCAN_WAVES) + 4 * BL_HIST_BINS == BL_FREQ_SCAN_LDS_BYTES &&
+/* every region of the layout, in order: [exchange buffers][twiddles 2 KB + pad 2 KB][Hann 2 KB][spectrum 1 KB][relay 64 B]
+ * [histogram] — each ends where the next begins, the histogram ends where the allocation ends (what the
+ * range-test-free ds_add of scan_hist_word relies on), and the kernel's launch passes exactly this size */
+#define BL_FREQ_TW_OFF(W) BL_FREQ_XCH_BYTES(W)
+#define BL_FREQ_HANN_OFF(W) (BL_FREQ_XCH_BYTES(W) + 2 * 256 * 8)
+#define BL_FREQ_RELAY_OFF(W) (BL_FREQ_ACC_OFF(W) + 256 * 4)
+static_assert(BL_FREQ_TW_OFF(BL_FREQ_SCAN_WAVES) + LV_TW_SLOTS * 16 * 8 <= BL_FREQ_HANN_OFF(BL_FREQ_SCAN_WAVES) &&
+                  BL_FREQ_HANN_OFF(BL_FREQ_SCAN_WAVES) + 512 * 4 == BL_FREQ_ACC_OFF(BL_FREQ_SCAN_WAVES) &&
+                  BL_FREQ_ACC_OFF(BL_FREQ_SCAN_WAVES) + 256 * 4 == BL_FREQ_RELAY_OFF(BL_FREQ_SCAN_WAVES) &&
+                  BL_FREQ_RELAY_OFF(BL_FREQ_SCAN_WAVES) + 64 == BL_FREQ_HIST_OFF(BL_FREQ_SCAN_WAVES) &&
+                  BL_FREQ_HIST_OFF(BL_FREQ_SCAN_WAVES) + 4 * BL_HIST_BINS == BL_FREQ_SCAN_LDS_BYTES &&
                   BL_FREQ_SCAN_LDS_BYTES <= 160 * 1024,
-              "k_freq_scan: the histogram must be the last object of the workgroup's LDS (scan_hist_word)");
+              "k_freq_scan: every LDS region ends where the next begins and the histogram is the LAST one (scan_hist_word)");
 #define BL_FREQ_SROW 264
 
 /* cross-lane move of a pair of floats through DPP (two 32-bit moves); CTRL 0x140 = row_mirror,
@@ -489,29 +499,41 @@ template <int CTRL> __device__ __forceinline__ bl_f2 bl_dpp_f2_old(bl_f2 old, bl
   return (bl_f2){__int_as_float(x), __int_as_float(y)};
 }
 
-/* WAVES waves per workgroup (one workgroup per song).  SCAN: the statistics pass rides along — every PCM word the
+/*
+ * WAVES waves per workgroup (one workgroup per song).  SCAN: the statistics pass rides along — every PCM word the
  * transform loads also goes into the song's sum, sum of squares and central histogram (k_pcm_scan's arithmetic),
- * so the analysis reads the PCM twice instead of three times. */
+ * so the analysis reads the PCM twice instead of three times.
+ *
+ * The transform is libavcodec's, node for node (bl_fft_lavc.h; round 6): what the reference's av_rdft_calc computes
+ * in the order it computes it, so that every frame's power values — and with them `frequency` — are the oracle's bit
+ * for bit (the oracle under that order prints the reference's golden values to the last digit, DESIGN.md section 6).
+ * The input is gathered in split-radix order (lane L register r = element (lv_base(L) + K[r]) mod 256 of the frame:
+ * immediate offsets from one per-lane base, every 8-byte element still loaded exactly once, 16 lanes per load inside
+ * a 16-element neighbourhood), the leaves (fft16, or fft8 twice) run in that layout, ONE transpose through the
+ * group's exchange buffer, then pass(32) with its products exchanged between lanes l and l ^ 8 by DPP, pass(64 .. 256)
+ * in registers, rdft.c's post-pass with the partner by DPP (row mirror + shift) and re * re + im * im unfused.
+ * Rounds 1-5 ran a fused radix-16 transform here (git 6a8cdc4: freq_frames_body; 558 instead of ~760 packed
+ * instructions per wave-iteration, k_freq_scan 8.77 instead of 9.64 ms per 1 024 S180 songs) whose `frequency` agreed
+ * with the oracle to a few 1e-6 absolute — inside the reference's own tolerance, not bit for bit.
+ */
 template <bool STEREO, int WAVES, bool SCAN>
-__device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm, const bl_dsong &sg,
+__device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm, const bl_dsong &sg,
                                                  const bl_tables &tb, float *spectrum, bl_dstats *st,
                                                  unsigned *gh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int FPI = 8 * WAVES; /* frames per workgroup iteration */
   c2p *xch = reinterpret_cast<c2p *>(smem); /* 4 WAVES x 272 */
-  c2f *tw256 = reinterpret_cast<c2f *>(smem + BL_FREQ_XCH_BYTES(WAVES));
-  c2f *tw512 = tw256 + 256;
-  float *hann = reinterpret_cast<float *>(tw512 + 256);
+  c2f *lvtw = reinterpret_cast<c2f *>(smem + BL_FREQ_TW_OFF(WAVES)); /* [LV_TW_SLOTS][16 lanes] */
+  float *hann = reinterpret_cast<float *>(smem + BL_FREQ_HANN_OFF(WAVES));
   float *accv = reinterpret_cast<float *>(smem + BL_FREQ_ACC_OFF(WAVES)); /* ps[0..255] so far */
   unsigned *lh = reinterpret_cast<unsigned *>(smem + BL_FREQ_HIST_OFF(WAVES)); /* SCAN: the histogram */
   typedef __attribute__((address_space(3))) volatile int lds_vint;
-  lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF(WAVES) + 256 * 4);
+  lds_vint *relay = (lds_vint *)(smem + BL_FREQ_RELAY_OFF(WAVES));
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, gl = g & 3;
   const int16_t *p = pcm + sg.pcm_off;
   if (WAVES == 4 || tid < 256) {
-    tw256[tid] = tb.tw256_f[((tid & 15) * (tid >> 4)) & 255]; /* [k1][n0] layout, see bl_fft.h */
-    tw512[tid] = tb.tw512_f[tid];
+    lvtw[tid] = tb.lv_tw[tid];
     hann[tid] = tb.hann[tid];
     hann[tid + 256] = tb.hann[tid + 256];
     accv[tid] = 0.f;
@@ -525,6 +547,17 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
   long long sum = 0;
   unsigned long long sq = 0;
 
+  /* this lane's place in the split-radix order (bl_fft_lavc.h): T8 lanes 1, 5, 7, 9, 13; base element lv_base(l),
+   * from which the lanes with base >= 251 wrap for every register but the first */
+  const bool t16 = ((0x22A2u >> l) & 1u) == 0u;
+  const unsigned long long bases = l < 8 ? 0x06FE0A02FC040800ull : 0xFB0307FFFD050901ull; /* lv_base(), a byte per lane */
+  const int base0 = (int)((bases >> (8 * (l & 7))) & 0xFFu);
+  const int basep = base0 >= 251 ? base0 - 256 : base0;
+  const bool lo8 = l < 8;
+  /* gather order of the registers: lv_k_lo | lv_k_hi(true, .) */
+  constexpr int KG[16] = {0, 128, 64, 192, 32, 160, 224, 96, 16, 144, 80, 208, 240, 112, 48, 176};
+  static_assert(lv_gather_index(3, 1) == ((252 + 128) & 255) && lv_gather_index(12, 0) == 255 && lv_base(15) == 251, "lv tables");
+
   c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* the transpose buffer of this 16-lane group */
   float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [8][BL_FREQ_SROW] */
   /* one iteration ahead: 32 unconditional loads per lane (frame indices clamped into the song;
@@ -532,23 +565,27 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
    * latency of iteration it+1 hides behind the transforms of iteration it */
   uint2 pa[16], pb[16];
   constexpr bool stereo = STEREO; /* the channel handling is compiled in; k_freq_frames picks per workgroup */
-  /* loads of rows [4 * part, 4 * part + 4) of both frames: the iteration issues its 32 loads in
+  /* loads of registers [4 * part, 4 * part + 4) of both frames: the iteration issues its 32 loads in
    * four instalments between the phases of the transform (32 at once fill the vector-memory
    * queue and the wave sits in front of it: 1.6 k cycles per iteration) */
   auto fetch = [&](int f_, int part) {
     const int fa = min(f_, sg.n_frames - 1), fb = min(f_ + 1, sg.n_frames - 1);
     if (stereo) {
-      const uint2 *qa = reinterpret_cast<const uint2 *>(p + (size_t)fa * 1024);
-      const uint2 *qb = reinterpret_cast<const uint2 *>(p + (size_t)fb * 1024);
+      const uint2 *qa = reinterpret_cast<const uint2 *>(p + (size_t)fa * 1024) + basep;
+      const uint2 *qb = reinterpret_cast<const uint2 *>(p + (size_t)fb * 1024) + basep;
 #pragma unroll
-      for (int m1 = 4 * part; m1 < 4 * part + 4; ++m1) { pa[m1] = qa[16 * m1 + l]; pb[m1] = qb[16 * m1 + l]; }
+      for (int r = 4 * part; r < 4 * part + 4; ++r) {
+        const int e = r == 0 ? base0 - basep : KG[r];
+        pa[r] = qa[e]; pb[r] = qb[e];
+      }
     } else {
-      const unsigned *qa = reinterpret_cast<const unsigned *>(p + (size_t)fa * 512);
-      const unsigned *qb = reinterpret_cast<const unsigned *>(p + (size_t)fb * 512);
+      const unsigned *qa = reinterpret_cast<const unsigned *>(p + (size_t)fa * 512) + basep;
+      const unsigned *qb = reinterpret_cast<const unsigned *>(p + (size_t)fb * 512) + basep;
 #pragma unroll
-      for (int m1 = 4 * part; m1 < 4 * part + 4; ++m1) {
-        pa[m1] = make_uint2(qa[16 * m1 + l], 0u);
-        pb[m1] = make_uint2(qb[16 * m1 + l], 0u);
+      for (int r = 4 * part; r < 4 * part + 4; ++r) {
+        const int e = r == 0 ? base0 - basep : KG[r];
+        pa[r] = make_uint2(qa[e], 0u);
+        pb[r] = make_uint2(qb[e], 0u);
       }
     }
   };
@@ -572,22 +609,27 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
       s1 = (bl_f2){(float)a1, (float)b1};
     }
   };
-  /* most of this lane's pass-1 twiddles W256^(l k1) stay in registers for the whole song (read
-   * from LDS inside the loop, each one put its latency in front of four dependent operations);
-   * the last three do come from LDS: with all 15 the kernel no longer fits 256 VGPRs */
-  constexpr int W1_REGS = 13;
-  c2f w1[W1_REGS];
+  auto bc = [](float w) { return (bl_f2){w, w}; };
+  /* the lane's twiddles of the in-register passes stay in registers for the whole song; pass(32)'s carries the sign
+   * of its half of the pair (lv_pass32_mul) */
+  const c2f w32 = lvtw[LV_TW_P32 * 16 + l], w64 = lvtw[LV_TW_P64 * 16 + l];
+  const float ws32 = lo8 ? -w32.im : w32.im;
+  c2f w128[2], w256[4];
 #pragma unroll
-  for (int k1 = 1; k1 < W1_REGS; ++k1) w1[k1] = tw256[k1 * 16 + l];
+  for (int q = 0; q < 2; ++q) w128[q] = lvtw[(LV_TW_P128 + q) * 16 + l];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w256[q] = lvtw[(LV_TW_P256 + q) * 16 + l];
+  const bl_f2 SH = bc(tb.lv_leafc[0]), C1 = bc(tb.lv_leafc[1]), C3 = bc(tb.lv_leafc[2]);
+  const bl_f2 *hann2 = reinterpret_cast<const bl_f2 *>(hann) + basep;
   const int n_iter = (sg.n_frames + FPI - 1) / FPI;
 #pragma unroll
   for (int part = 0; part < 4; ++part) fetch(8 * wave + 2 * gl, part);
   for (int it = 0; it < n_iter; ++it) {
     const int f = it * FPI + 8 * wave + 2 * gl;
     /* SCAN: the input stage with the statistics (a third of the iteration's instructions and all of its LDS
-     * atomics) runs at priority 3, the first transform pass at 2, the rest at 0: of the two waves of a SIMD the one
-     * that is feeding the LDS wins the VALU.  32.6 vs 33.8 ms per 4 096 songs; the other orders (later phases
-     * first, as in k_env_windows3) made no difference, and k_freq_frames gains nothing from any (Appendix A). */
+     * atomics) runs at priority 3, the leaves at 2, the rest at 0: of the two waves of a SIMD the one
+     * that is feeding the LDS wins the VALU.  32.6 vs 33.8 ms per 4 096 songs (round 4); the other orders (later
+     * phases first, as in k_env_windows3) made no difference, and k_freq_frames gains nothing from any. */
     if (SCAN) __builtin_amdgcn_s_setprio(3);
     bl_f2 re[16], im[16];
     /* SCAN: the statistics of every word as the transform's input stage consumes it (its registers die here).  The
@@ -598,71 +640,77 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     const bool full = it + 1 < n_iter; /* wave-uniform */
     const bool va = f < sg.n_frames, vb = f + 1 < sg.n_frames;
 #pragma unroll
-    for (int m1 = 0; m1 < 16; ++m1) {
-      const int d = 32 * m1 + 2 * l;
-      bl_f2 r, i;
+    for (int r = 0; r < 16; ++r) {
+      bl_f2 xr, xi;
       if (SCAN) {
         if (full) {
-          word(pa[m1].x); word(pb[m1].x);
-          if (stereo) { word(pa[m1].y); word(pb[m1].y); }
+          word(pa[r].x); word(pb[r].x);
+          if (stereo) { word(pa[r].y); word(pb[r].y); }
         } else {
-          if (va) { word(pa[m1].x); if (stereo) word(pa[m1].y); }
-          if (vb) { word(pb[m1].x); if (stereo) word(pb[m1].y); }
+          if (va) { word(pa[r].x); if (stereo) word(pa[r].y); }
+          if (vb) { word(pb[r].x); if (stereo) word(pb[r].y); }
         }
       }
-      mono2(pa[m1], pb[m1], r, i);
-      const bl_f2 h = *reinterpret_cast<const bl_f2 *>(hann + d); /* hann[d], hann[d + 1] */
-      re[m1] = r * (bl_f2){h.x, h.x};
-      im[m1] = i * (bl_f2){h.y, h.y};
+      mono2(pa[r], pb[r], xr, xi);
+      const bl_f2 h = hann2[r == 0 ? base0 - basep : KG[r]]; /* hann[2 m], hann[2 m + 1] of this register's element m */
+      re[r] = xr * (bl_f2){h.x, h.x};
+      im[r] = xi * (bl_f2){h.y, h.y};
     }
     if (SCAN) sum += s32;
     fetch(f + FPI, 0);
-    /* the exchange buffers of a 16-lane group are private to it, hence to its wave */
     if (SCAN) __builtin_amdgcn_s_setprio(2);
-    bl_fft16(re, im);
+    lv_leaves<bl_f2>(t16, re, im, SH, C1, C3);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-      const int ps = bl_pos16(k1);
-      bl_f2 r = re[ps], i = im[ps];
-      if (k1 != 0) {
-        const c2f w = k1 < W1_REGS ? w1[k1] : tw256[k1 * 16 + l];
-        bl_cmul(r, i, (bl_f2){w.re, w.re}, (bl_f2){w.im, w.im}); /* lane 0: w = 1 exactly */
-      }
-      c2p v; v.re = r; v.im = i;
-      gx[k1 * 17 + l] = v;
+    for (int r = 0; r < 16; ++r) {
+      c2p v; v.re = re[r]; v.im = im[r];
+      gx[r * 17 + l] = v;
     }
     bl_wave_sync();
     fetch(f + FPI, 1);
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) {
-      const c2p v = gx[l * 17 + n0];
-      re[n0] = v.re; im[n0] = v.im;
+    for (int j = 0; j < 16; ++j) {
+      const c2p v = gx[l * 17 + j];
+      re[j] = v.re; im[j] = v.im;
     }
     bl_wave_sync();
     fetch(f + FPI, 2);
     if (SCAN) __builtin_amdgcn_s_setprio(0);
-    bl_fft16(re, im);
+    { /* pass(32) @ 0, 64, 96, 128, 192: registers (R, R + 1), lanes l and l ^ 8 */
+      auto sel = [&](bl_f2 a, bl_f2 b) { return lo8 ? a : b; };
+      constexpr int R32[5] = {0, 4, 6, 8, 12};
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int R = R32[b];
+        bl_f2 tA, tB;
+        lv_pass32_mul<bl_f2>(re[R + 1], im[R + 1], bc(w32.re), bc(ws32), tA, tB);
+        const bl_f2 pA = bl_dpp_f2<0x128>(tA), pB = bl_dpp_f2<0x128>(tB); /* row_ror:8 = lane ^ 8 */
+        lv_pass32_fin<bl_f2>(re[R], im[R], re[R + 1], im[R + 1], tA, tB, pA, pB, sel);
+      }
+    }
+    lv_pass_inlane<bl_f2, 0, 1>(re, im, bc(w64.re), bc(w64.im));
+    lv_pass_inlane<bl_f2, 8, 1>(re, im, bc(w64.re), bc(w64.im));
+    lv_pass_inlane<bl_f2, 12, 1>(re, im, bc(w64.re), bc(w64.im));
+    lv_pass_inlane<bl_f2, 0, 2>(re, im, bc(w128[0].re), bc(w128[0].im));
+    lv_pass_inlane<bl_f2, 1, 2>(re, im, bc(w128[1].re), bc(w128[1].im));
+    lv_pass_inlane<bl_f2, 0, 4>(re, im, bc(w256[0].re), bc(w256[0].im));
+    lv_pass_inlane<bl_f2, 1, 4>(re, im, bc(w256[1].re), bc(w256[1].im));
+    lv_pass_inlane<bl_f2, 2, 4>(re, im, bc(w256[2].re), bc(w256[2].im));
+    lv_pass_inlane<bl_f2, 3, 4>(re, im, bc(w256[3].re), bc(w256[3].im));
     fetch(f + FPI, 3);
-    /* the partner of pair k = k1 + 16 k0 is Z[256 - k]: register 15 - k0 of lane (16 - k1) mod 16,
-     * fetched by a mirror of the 16-lane row and a shift by one (DPP), not through LDS; lane 0
-     * is its own partner and takes its register 16 - k0 (k0 = 0: Z[0] itself) */
+    /* rdft.c's post-pass: the partner of i = l + 16 j is Z[256 - i], register 15 - j of lane 16 - l (row mirror +
+     * shift by one); lane 0 is its own partner and takes its register 16 - j */
     bl_f2 own[8], mir[8];
 #pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) {
-      const bl_f2 zr = k0 ? re[bl_pos16(16 - k0)] : re[bl_pos16(0)];
-      const bl_f2 zi = k0 ? im[bl_pos16(16 - k0)] : im[bl_pos16(0)];
-      /* row_mirror, then a shift by one inside the row: lane 0 has no source there and keeps `old`,
-       * its own register — which is what it needs */
-      const bl_f2 pr = bl_dpp_f2_old<0x111>(zr, bl_dpp_f2<0x140>(re[bl_pos16(15 - k0)]));
-      const bl_f2 pi = bl_dpp_f2_old<0x111>(zi, bl_dpp_f2<0x140>(im[bl_pos16(15 - k0)]));
-      const c2f w = tw512[l + 16 * k0];
-      c2p wp; wp.re = (bl_f2){w.re, w.re}; wp.im = (bl_f2){w.im, w.im};
-      bl_fft512_power1<bl_f2>(re[bl_pos16(k0)], im[bl_pos16(k0)], pr, pi, wp, own[k0], mir[k0]);
+    for (int j = 0; j < 8; ++j) {
+      const bl_f2 zr = j ? re[16 - j] : re[0];
+      const bl_f2 zi = j ? im[16 - j] : im[0];
+      const bl_f2 pr = bl_dpp_f2_old<0x111>(zr, bl_dpp_f2<0x140>(re[15 - j]));
+      const bl_f2 pi = bl_dpp_f2_old<0x111>(zi, bl_dpp_f2<0x140>(im[15 - j]));
+      const c2f w = lvtw[(LV_TW_POST + j) * 16 + l];
+      lv_post_power<bl_f2>(re[j], im[j], pr, pi, bc(w.re), bc(w.im), bc(0.5f), own[j], mir[j]);
     }
-    const bl_f2 mr = re[bl_pos16(8)], mi = im[bl_pos16(8)];
-    const bl_f2 mid = bl_fma(mr, mr, mi * mi);
-    /* the transposed rows were read before the second pass: the wave's exchange space is free for `stage` */
-    /* ref :88-93: re*re + im*im of bin d, for d = 1..255 */
+    const bl_f2 mid = lv_mid_power<bl_f2>(re[8], im[8]);
+    /* ref :88-93: re*re + im*im of bin d, for d = 1..255 (lane 0's own[0] / mir[0] are bins 0 / 256: never read) */
     float *sa = stage + (2 * gl) * BL_FREQ_SROW, *sb = sa + BL_FREQ_SROW;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -671,7 +719,7 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     }
     if (l == 0) { sa[128] = mid.x; sb[128] = mid.y; }
     bl_wave_sync();
-    /* the baton: frames 32 it + 8 w .. + 7 join the running spectrum after those of wave w - 1 */
+    /* the baton: frames 8 WAVES it + 8 w .. + 7 join the running spectrum after those of wave w - 1 */
     const int turn = WAVES * it + wave;
     /* frames beyond the song's last one (their loads were clamped onto it) are not added */
     const int n_live = sg.n_frames - (it * FPI + 8 * wave);
@@ -740,279 +788,14 @@ __device__ __forceinline__ void freq_frames_body(const int16_t *__restrict__ pcm
     for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) gh[i] = lh[i]; /* the workgroup owns the song: plain stores */
 }
 
-/*
- * The same pass with the transform in libavcodec's operation order (bl_fft_lavc.h): what the reference's
- * av_rdft_calc computes node for node, so that the power values — and with them `frequency` — are the oracle's bit
- * for bit (the oracle under that order prints the reference's golden values to the last digit, DESIGN.md section 6).
- * Differences to freq_frames_body: the input is gathered in split-radix order (lane L register r = element
- * (lv_base(L) + K[r]) mod 256 of the frame: immediate offsets from one per-lane base, every 8-byte element still
- * loaded exactly once, 16 lanes per load inside a 16-element neighbourhood), the leaves run in that layout, ONE
- * transpose, then pass(32) with its products exchanged between lanes l and l ^ 8 by DPP, pass(64 .. 256) in
- * registers, rdft.c's post-pass with the partner by DPP as before, and re * re + im * im unfused.  Everything around
- * the transform — prefetch, statistics, staging, the baton — is freq_frames_body's.
- */
-template <bool STEREO, int WAVES, bool SCAN>
-__device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm, const bl_dsong &sg,
-                                                 const bl_tables &tb, float *spectrum, bl_dstats *st,
-                                                 unsigned *gh) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int FPI = 8 * WAVES; /* frames per workgroup iteration */
-  c2p *xch = reinterpret_cast<c2p *>(smem); /* 4 WAVES x 272 */
-  c2f *lvtw = reinterpret_cast<c2f *>(smem + BL_FREQ_XCH_BYTES(WAVES)); /* [LV_TW_SLOTS][16 lanes] */
-  float *hann = reinterpret_cast<float *>(smem + BL_FREQ_XCH_BYTES(WAVES) + 2 * 256 * 8);
-  float *accv = reinterpret_cast<float *>(smem + BL_FREQ_ACC_OFF(WAVES)); /* ps[0..255] so far */
-  unsigned *lh = reinterpret_cast<unsigned *>(smem + BL_FREQ_HIST_OFF(WAVES)); /* SCAN: the histogram */
-  typedef __attribute__((address_space(3))) volatile int lds_vint;
-  lds_vint *relay = (lds_vint *)(smem + BL_FREQ_ACC_OFF(WAVES) + 256 * 4);
-  const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, gl = g & 3;
-  const int16_t *p = pcm + sg.pcm_off;
-  if (WAVES == 4 || tid < 256) {
-    lvtw[tid] = tb.lv_tw[tid];
-    hann[tid] = tb.hann[tid];
-    hann[tid + 256] = tb.hann[tid + 256];
-    accv[tid] = 0.f;
-  }
-  if (SCAN)
-    for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) lh[i] = 0;
-  if (tid == 0) relay[0] = 0;
-  __syncthreads();
-  unsigned lds_hist = (unsigned)(size_t)(bl_lds_u32 *)lh;
-  asm volatile("" : "+v"(lds_hist)); /* lives in a VGPR: as a scalar it is copied in front of every use */
-  long long sum = 0;
-  unsigned long long sq = 0;
-
-  /* this lane's place in the split-radix order (bl_fft_lavc.h): T8 lanes 1, 5, 7, 9, 13; base element lv_base(l),
-   * from which the lanes with base >= 251 wrap for every register but the first */
-  const bool t16 = ((0x22A2u >> l) & 1u) == 0u;
-  const unsigned long long bases = l < 8 ? 0x06FE0A02FC040800ull : 0xFB0307FFFD050901ull; /* lv_base(), a byte per lane */
-  const int base0 = (int)((bases >> (8 * (l & 7))) & 0xFFu);
-  const int basep = base0 >= 251 ? base0 - 256 : base0;
-  const bool lo8 = l < 8;
-  /* gather order of the registers: lv_k_lo | lv_k_hi(true, .) */
-  constexpr int KG[16] = {0, 128, 64, 192, 32, 160, 224, 96, 16, 144, 80, 208, 240, 112, 48, 176};
-  static_assert(lv_gather_index(3, 1) == ((252 + 128) & 255) && lv_gather_index(12, 0) == 255 && lv_base(15) == 251, "lv tables");
-
-  c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* the transpose buffer of this 16-lane group */
-  float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [8][BL_FREQ_SROW] */
-  uint2 pa[16], pb[16];
-  constexpr bool stereo = STEREO;
-  auto fetch = [&](int f_, int part) {
-    const int fa = min(f_, sg.n_frames - 1), fb = min(f_ + 1, sg.n_frames - 1);
-    if (stereo) {
-      const uint2 *qa = reinterpret_cast<const uint2 *>(p + (size_t)fa * 1024) + basep;
-      const uint2 *qb = reinterpret_cast<const uint2 *>(p + (size_t)fb * 1024) + basep;
-#pragma unroll
-      for (int r = 4 * part; r < 4 * part + 4; ++r) {
-        const int e = r == 0 ? base0 - basep : KG[r];
-        pa[r] = qa[e]; pb[r] = qb[e];
-      }
-    } else {
-      const unsigned *qa = reinterpret_cast<const unsigned *>(p + (size_t)fa * 512) + basep;
-      const unsigned *qb = reinterpret_cast<const unsigned *>(p + (size_t)fb * 512) + basep;
-#pragma unroll
-      for (int r = 4 * part; r < 4 * part + 4; ++r) {
-        const int e = r == 0 ? base0 - basep : KG[r];
-        pa[r] = make_uint2(qa[e], 0u);
-        pb[r] = make_uint2(qb[e], 0u);
-      }
-    }
-  };
-  auto mono2 = [&](const uint2 wa, const uint2 wb, bl_f2 &s0, bl_f2 &s1) { /* see freq_frames_body */
-    const int a0 = (int)(short)(wa.x & 0xFFFFu), a1 = (int)(short)(wa.x >> 16);
-    const int b0 = (int)(short)(wb.x & 0xFFFFu), b1 = (int)(short)(wb.x >> 16);
-    if (stereo) {
-      const int a2 = (int)(short)(wa.y & 0xFFFFu), a3 = (int)(short)(wa.y >> 16);
-      const int b2 = (int)(short)(wb.y & 0xFFFFu), b3 = (int)(short)(wb.y >> 16);
-      const bl_f2 h0 = (bl_f2){(float)(a0 + a1), (float)(b0 + b1)} * 0.5f;
-      const bl_f2 h1 = (bl_f2){(float)(a2 + a3), (float)(b2 + b3)} * 0.5f;
-      s0 = (bl_f2){__builtin_truncf(h0.x), __builtin_truncf(h0.y)};
-      s1 = (bl_f2){__builtin_truncf(h1.x), __builtin_truncf(h1.y)};
-    } else {
-      s0 = (bl_f2){(float)a0, (float)b0};
-      s1 = (bl_f2){(float)a1, (float)b1};
-    }
-  };
-  auto bc = [](float w) { return (bl_f2){w, w}; };
-  /* the lane's twiddles of the in-register passes stay in registers for the whole song; pass(32)'s carries the sign
-   * of its half of the pair (lv_pass32_mul) */
-  const c2f w32 = lvtw[LV_TW_P32 * 16 + l], w64 = lvtw[LV_TW_P64 * 16 + l];
-  const float ws32 = lo8 ? -w32.im : w32.im;
-  c2f w128[2], w256[4];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) w128[q] = lvtw[(LV_TW_P128 + q) * 16 + l];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) w256[q] = lvtw[(LV_TW_P256 + q) * 16 + l];
-  const bl_f2 SH = bc(tb.lv_leafc[0]), C1 = bc(tb.lv_leafc[1]), C3 = bc(tb.lv_leafc[2]);
-  const bl_f2 *hann2 = reinterpret_cast<const bl_f2 *>(hann) + basep;
-  const int n_iter = (sg.n_frames + FPI - 1) / FPI;
-#pragma unroll
-  for (int part = 0; part < 4; ++part) fetch(8 * wave + 2 * gl, part);
-  for (int it = 0; it < n_iter; ++it) {
-    const int f = it * FPI + 8 * wave + 2 * gl;
-    if (SCAN) __builtin_amdgcn_s_setprio(3);
-    bl_f2 re[16], im[16];
-    int s32 = 0;
-    auto word = [&](unsigned w) { scan_word(w, s32, sq, lds_hist, true); };
-    const bool full = it + 1 < n_iter; /* wave-uniform */
-    const bool va = f < sg.n_frames, vb = f + 1 < sg.n_frames;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      bl_f2 xr, xi;
-      if (SCAN) {
-        if (full) {
-          word(pa[r].x); word(pb[r].x);
-          if (stereo) { word(pa[r].y); word(pb[r].y); }
-        } else {
-          if (va) { word(pa[r].x); if (stereo) word(pa[r].y); }
-          if (vb) { word(pb[r].x); if (stereo) word(pb[r].y); }
-        }
-      }
-      mono2(pa[r], pb[r], xr, xi);
-      const bl_f2 h = hann2[r == 0 ? base0 - basep : KG[r]]; /* hann[2 m], hann[2 m + 1] of this register's element m */
-      re[r] = xr * (bl_f2){h.x, h.x};
-      im[r] = xi * (bl_f2){h.y, h.y};
-    }
-    if (SCAN) sum += s32;
-    fetch(f + FPI, 0);
-    if (SCAN) __builtin_amdgcn_s_setprio(2);
-    lv_leaves<bl_f2>(t16, re, im, SH, C1, C3);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      c2p v; v.re = re[r]; v.im = im[r];
-      gx[r * 17 + l] = v;
-    }
-    bl_wave_sync();
-    fetch(f + FPI, 1);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const c2p v = gx[l * 17 + j];
-      re[j] = v.re; im[j] = v.im;
-    }
-    bl_wave_sync();
-    fetch(f + FPI, 2);
-    if (SCAN) __builtin_amdgcn_s_setprio(0);
-    { /* pass(32) @ 0, 64, 96, 128, 192: registers (R, R + 1), lanes l and l ^ 8 */
-      auto sel = [&](bl_f2 a, bl_f2 b) { return lo8 ? a : b; };
-      constexpr int R32[5] = {0, 4, 6, 8, 12};
-#pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        const int R = R32[b];
-        bl_f2 tA, tB;
-        lv_pass32_mul<bl_f2>(re[R + 1], im[R + 1], bc(w32.re), bc(ws32), tA, tB);
-        const bl_f2 pA = bl_dpp_f2<0x128>(tA), pB = bl_dpp_f2<0x128>(tB); /* row_ror:8 = lane ^ 8 */
-        lv_pass32_fin<bl_f2>(re[R], im[R], re[R + 1], im[R + 1], tA, tB, pA, pB, sel);
-      }
-    }
-    lv_pass_inlane<bl_f2, 0, 1>(re, im, bc(w64.re), bc(w64.im));
-    lv_pass_inlane<bl_f2, 8, 1>(re, im, bc(w64.re), bc(w64.im));
-    lv_pass_inlane<bl_f2, 12, 1>(re, im, bc(w64.re), bc(w64.im));
-    lv_pass_inlane<bl_f2, 0, 2>(re, im, bc(w128[0].re), bc(w128[0].im));
-    lv_pass_inlane<bl_f2, 1, 2>(re, im, bc(w128[1].re), bc(w128[1].im));
-    lv_pass_inlane<bl_f2, 0, 4>(re, im, bc(w256[0].re), bc(w256[0].im));
-    lv_pass_inlane<bl_f2, 1, 4>(re, im, bc(w256[1].re), bc(w256[1].im));
-    lv_pass_inlane<bl_f2, 2, 4>(re, im, bc(w256[2].re), bc(w256[2].im));
-    lv_pass_inlane<bl_f2, 3, 4>(re, im, bc(w256[3].re), bc(w256[3].im));
-    fetch(f + FPI, 3);
-    /* rdft.c's post-pass: the partner of i = l + 16 j is Z[256 - i], register 15 - j of lane 16 - l (row mirror +
-     * shift by one, as in freq_frames_body); lane 0 is its own partner and takes its register 16 - j */
-    bl_f2 own[8], mir[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bl_f2 zr = j ? re[16 - j] : re[0];
-      const bl_f2 zi = j ? im[16 - j] : im[0];
-      const bl_f2 pr = bl_dpp_f2_old<0x111>(zr, bl_dpp_f2<0x140>(re[15 - j]));
-      const bl_f2 pi = bl_dpp_f2_old<0x111>(zi, bl_dpp_f2<0x140>(im[15 - j]));
-      const c2f w = lvtw[(LV_TW_POST + j) * 16 + l];
-      lv_post_power<bl_f2>(re[j], im[j], pr, pi, bc(w.re), bc(w.im), bc(0.5f), own[j], mir[j]);
-    }
-    const bl_f2 mid = lv_mid_power<bl_f2>(re[8], im[8]);
-    /* ref :88-93: re*re + im*im of bin d, for d = 1..255 (lane 0's own[0] / mir[0] are bins 0 / 256: never read) */
-    float *sa = stage + (2 * gl) * BL_FREQ_SROW, *sb = sa + BL_FREQ_SROW;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      sa[l + 16 * k] = own[k].x; sb[l + 16 * k] = own[k].y;
-      sa[256 - l - 16 * k] = mir[k].x; sb[256 - l - 16 * k] = mir[k].y;
-    }
-    if (l == 0) { sa[128] = mid.x; sb[128] = mid.y; }
-    bl_wave_sync();
-    const int turn = WAVES * it + wave;
-    const int n_live = sg.n_frames - (it * FPI + 8 * wave);
-    float sv[4][8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int fr = 0; fr < 8; ++fr) sv[q][fr] = stage[fr * BL_FREQ_SROW + lane + 64 * q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    while (__builtin_amdgcn_readfirstlane(relay[0]) < turn) __builtin_amdgcn_s_sleep(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = accv[lane + 64 * q];
-    if (n_live >= 8) {
-#pragma unroll
-      for (int fr = 0; fr < 8; ++fr)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[q] += sv[q][fr];
-          asm volatile("" : "+v"(acc[q]));
-        }
-    } else {
-#pragma unroll
-      for (int fr = 0; fr < 8; ++fr)
-        if (fr < n_live) { /* wave-uniform */
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] += sv[q][fr];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) accv[lane + 64 * q] = acc[q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    bl_wave_sync();
-    if (lane == 0) relay[0] = turn + 1;
-  }
-  if (SCAN) {
-    for (int i = sg.n_frames * 512 * sg.channels + tid; i < sg.n; i += 64 * WAVES) {
-      const int sv = (int)p[i];
-      sum += sv;
-      sq += (unsigned)(sv * sv);
-      const unsigned b = (unsigned)(sv + BL_HIST_BINS / 2);
-      if (b < BL_HIST_BINS) atomicAdd(&lh[b], 1u);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      sum += __shfl_down(sum, off);
-      sq += __shfl_down(sq, off);
-    }
-    if (lane == 0) {
-      atomicAdd(&st->sum, (unsigned long long)sum);
-      atomicAdd(&st->sumsq, sq);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  if (WAVES == 4 || tid < 256) spectrum[(size_t)blockIdx.x * 256 + tid] = accv[tid];
-  if (SCAN)
-    for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) gh[i] = lh[i];
-}
-
-#ifndef BL_FREQ_LAVC
-#define BL_FREQ_LAVC 1 /* 0: the fused radix-16 transform of rounds 1-5 (freq_frames_body), for A/B measurements */
-#endif
-#if BL_FREQ_LAVC
-#define BL_FREQ_BODY freq_frames_lavc
-#else
-#define BL_FREQ_BODY freq_frames_body
-#endif
-
 /* one workgroup per song; the channel count is uniform per workgroup, so the branch costs one
  * scalar compare and each path keeps its compiled-in input side */
 __global__ __launch_bounds__(256, 2) void k_freq_frames(const int16_t *__restrict__ pcm,
                                                         const bl_dsong *__restrict__ songs,
                                                         bl_tables tb, float *spectrum) {
   const bl_dsong sg = songs[blockIdx.x];
-  if (sg.channels == 2) BL_FREQ_BODY<true, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
-  else BL_FREQ_BODY<false, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
+  if (sg.channels == 2) freq_frames_lavc<true, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
+  else freq_frames_lavc<false, 4, false>(pcm, sg, tb, spectrum, nullptr, nullptr);
 }
 
 /* k_freq_scan: k_freq_frames and k_pcm_scan in one pass over the PCM — one 512-thread workgroup per song and CU
@@ -1024,8 +807,8 @@ __global__ __launch_bounds__(64 * BL_FREQ_SCAN_WAVES) void k_freq_scan(const int
   const bl_dsong sg = songs[blockIdx.x];
   bl_dstats *st = stats + blockIdx.x;
   unsigned *gh = hist + (size_t)blockIdx.x * BL_HIST_BINS;
-  if (sg.channels == 2) BL_FREQ_BODY<true, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
-  else BL_FREQ_BODY<false, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
+  if (sg.channels == 2) freq_frames_lavc<true, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
+  else freq_frames_lavc<false, BL_FREQ_SCAN_WAVES, true>(pcm, sg, tb, spectrum, st, gh);
 }
 
 __global__ __launch_bounds__(256) void k_freq_finish(const float *__restrict__ spectrum,
@@ -1424,6 +1207,12 @@ __global__ __launch_bounds__(64 * (EV_CWAVES + 1)) void k_env_windows3(
    * Two VALU instructions per round instead of the 21 that clamped 64-bit addresses took (round 5). */
   uint4 pre[4];
   short preh;
+  /* descriptor word 3 = 0x00020000 (DATA_FORMAT 32) and "out of range reads as zero" are the gfx9 / CDNA raw-buffer
+   * rules; num_records and the offsets are 32-bit byte counts: a song is at most INT_MAX samples (bl_dsong::n is an
+   * int), so 2 * n_used < 2^32 */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_env_windows3: the raw-buffer descriptor and its range check are written for gfx950"
+#endif
   const __amdgpu_buffer_rsrc_t prs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t *>(p), 0, (int)(2u * (unsigned)n_used), 0x00020000);
   unsigned voff = 2u * (unsigned)(1024 * r0 + 240 + 16 * ln);  /* first input = first output - 16 */
@@ -2052,21 +1841,17 @@ __global__ __launch_bounds__(256) void k_extract_vecs(const bl_amd_song_result *
 /* ========================================================================= */
 /* launchers (declared in bl_launch.h)                                        */
 
-size_t blk_tables_bytes(void) { return 256 * 16 * 2 + 256 * 8 * 2 + 512 * 4 + LV_TW_SLOTS * 16 * 8; }
+size_t blk_tables_bytes(void) { return 256 * 16 * 2 + 512 * 4 + LV_TW_SLOTS * 16 * 8; }
 
 void blk_tables_fill_host(unsigned char *h) {
   /* twiddle / window tables, computed in double on the host */
   const double pi = 3.14159265358979323846;
   c2d *t256 = reinterpret_cast<c2d *>(h);
   c2d *t512 = t256 + 256;
-  c2f *f256 = reinterpret_cast<c2f *>(t512 + 256);
-  c2f *f512 = f256 + 256;
-  float *hann = reinterpret_cast<float *>(f512 + 256);
+  float *hann = reinterpret_cast<float *>(t512 + 256);
   for (int k = 0; k < 256; ++k) {
     t256[k].re = cos(2 * pi * k / 256); t256[k].im = -sin(2 * pi * k / 256);
     t512[k].re = cos(2 * pi * k / 512); t512[k].im = -sin(2 * pi * k / 512);
-    f256[k].re = (float)t256[k].re; f256[k].im = (float)t256[k].im;
-    f512[k].re = (float)t512[k].re; f512[k].im = (float)t512[k].im;
   }
   /* ref frequency_sort.c:40-42 */
   for (int i = 0; i < 512; ++i) hann[i] = (float)(.5f * (1.0f - cos(2 * M_PI * i / (512 - 1))));
@@ -2080,9 +1865,7 @@ bl_tables blk_tables_bind(const void *d_mem) {
   const unsigned char *d = static_cast<const unsigned char *>(d_mem);
   tb.tw256_d = reinterpret_cast<const c2d *>(d);
   tb.tw512_d = tb.tw256_d + 256;
-  tb.tw256_f = reinterpret_cast<const c2f *>(tb.tw512_d + 256);
-  tb.tw512_f = tb.tw256_f + 256;
-  tb.hann = reinterpret_cast<const float *>(tb.tw512_f + 256);
+  tb.hann = reinterpret_cast<const float *>(tb.tw512_d + 256);
   tb.lv_tw = reinterpret_cast<const c2f *>(tb.hann + 512);
   {
     float tw[LV_TW_SLOTS * 16][2];

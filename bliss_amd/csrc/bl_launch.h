@@ -50,7 +50,6 @@ typedef bl_c2<float> c2f;
 
 struct bl_tables {
   const c2d *tw256_d, *tw512_d;
-  const c2f *tw256_f, *tw512_f;
   const float *hann;
   const c2f *lv_tw;   /* bl_fft_lavc.h: [LV_TW_SLOTS][16 lanes] (cos, "sin") pairs of libavcodec's tables */
   float lv_leafc[4];  /* sqrthalf, cos_16[1], cos_16[3] */

@@ -29,6 +29,11 @@ def check_song(got, ref, tag):
     # the exactly-ordered parts of the path: bit-identical expected
     assert np.float32(got["amplitude"]) == np.float32(ref["amplitude"]), (tag, "amplitude bits")
     assert np.float32(got["tempo"]) == np.float32(ref["tempo"]), (tag, "tempo bits")
+    # since round 6 that includes the frequency analysis: the kernel's f32 DFT evaluates libavcodec's operation order
+    # node for node (bl_fft_lavc.h), as the oracle does (orc_fft_lavc.c) — every frame's power spectrum, their ordered
+    # f32 sum, the peak, the rating and with it the force
+    for k in ("frequency", "freq_peak", "force"):
+        assert np.float32(got[k]).view(np.int32) == np.float32(ref[k]).view(np.int32), (tag, k + " bits", float(got[k]), float(ref[k]))
     assert abs(float(got["atk_sum"]) - ref["atk_sum"]) <= 1e-9 * abs(ref["atk_sum"]), (tag, "atk_sum")
     assert int(got["status"]) == 0
 
@@ -101,8 +106,11 @@ def test_reference_golden_through_bl_analyze(gpu_lib):
     gold = dict(force=-20.777929, tempo=-8.945454, amplitude=-10.641844, frequency=-10.136086,
                 attack=-15.560563)
     assert abs(song.force - gold["force"]) <= 1e-5
+    assert "%.6f" % song.force == "%.6f" % gold["force"]
     for k in ("tempo", "amplitude", "frequency", "attack"):
         assert abs(getattr(song.force_vector, k) - gold[k]) <= 1e-5, k
+        # to the last digit the reference's test prints (round 6: all five, through the HIP path)
+        assert "%.6f" % getattr(song.force_vector, k) == "%.6f" % gold[k], (k, getattr(song.force_vector, k))
     assert (song.channels, song.nSamples, song.sample_rate, song.bitrate,
             song.nb_bytes_per_sample, song.duration) == (2, 488138, 22050, 233864, 2, 11)
     n = song.nSamples
@@ -127,8 +135,10 @@ def test_reference_golden_s32_through_bl_analyze(gpu_lib):
     gold = dict(force=-20.821571, tempo=-8.218182, amplitude=-10.641695, frequency=-10.179875,
                 attack=-15.561186)
     assert abs(song.force - gold["force"]) <= 1e-5
+    assert "%.6f" % song.force == "%.6f" % gold["force"]
     for k in ("tempo", "amplitude", "frequency", "attack"):
         assert abs(getattr(song.force_vector, k) - gold[k]) <= 1e-5, k
+        assert "%.6f" % getattr(song.force_vector, k) == "%.6f" % gold[k], (k, getattr(song.force_vector, k))
     assert (song.channels, song.nSamples, song.sample_rate, song.nb_bytes_per_sample,
             song.duration, song.resampled) == (2, 488140, 22050, 2, 11, 1)
     assert (song.artist, song.title, song.album, song.tracknumber, song.genre) == \
@@ -589,3 +599,23 @@ def test_sqrt_of_the_distance_kernels_is_correctly_rounded(gpu_lib):
     # [2^-100, 2^126]: 226 binades of 2^23 values and the upper end point
     assert checked == 226 * (1 << 23) + 1, checked
     assert bad_fast == 0 and bad_slow == 0, (bad_fast, bad_slow)
+
+
+def test_checked_histogram_build_gives_the_same_records(gpu_lib):
+    """INTEGRATION.md advertises `make checked` (-DBL_AMD_CHECKED_HIST: range-tested histogram adds instead of the
+    out-of-range ds_add the LDS discards): the build must exist, load, and pass the very tests that pin the unchecked
+    form — the out-of-range samples, the batch against the oracle — run here in a child process on
+    libbliss_amd_checked.so."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(HERE), "bliss_amd", "libbliss_amd_checked.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(os.path.dirname(HERE), "bliss_amd", "csrc"), "checked"], check=True,
+                       stdout=subprocess.DEVNULL)
+    env = dict(os.environ, BLISS_AMD_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_histogram_out_of_range_samples_are_dropped or test_batch_matches_oracle or "
+                        "test_reference_golden_through_bl_analyze", "-p", "no:cacheprovider"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
