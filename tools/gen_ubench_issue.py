@@ -127,6 +127,16 @@ body("lds_read_b128", [f"ds_read_b128 v[{64 + 4 * (i % 8)}:{67 + 4 * (i % 8)}], 
      n_valu=16, note="16 ds_read_b128 then wait; per read")
 body("lds_write_b128", [f"ds_write_b128 v11, v[{32 + 4 * (i % 8)}:{35 + 4 * (i % 8)}]" + (f" offset:{1024 * (i % 8)}" if i % 8 else "") for i in range(16)] + ["s_waitcnt lgkmcnt(0)"],
      n_valu=16, note="16 ds_write_b128 then wait; per write")
+# gfx950-only lane swaps: would they carry the half-wave hand-overs of the window kernel cheaper
+# than DPP moves?  v_permlane16_swap exchanges the odd rows of vdst with the even rows of src, v_permlane32_swap the upper
+# half of vdst with the lower half of src: both move ACROSS 16-lane rows, the kernel's exchanges are inside a row
+body("permlane16_swap", [f"v_permlane16_swap_b32 v{64 + (i % 32)}, v{32 + (i % 32)}" for i in range(64)], note="swap odd rows of vdst with even rows of src")
+body("permlane32_swap", [f"v_permlane32_swap_b32 v{64 + (i % 32)}, v{32 + (i % 32)}" for i in range(64)], note="swap upper half of vdst with lower half of src")
+# plain and packed f32 arithmetic of the frequency pass (bl_fft_lavc.h: v_pk_mul / v_pk_add, fused-DPP adds were an option)
+body("add_f32", [f"v_add_f32 v{64 + (i % 32)}, v{32 + (i % 32)}, v{64 + (i % 32)}" for i in range(64)])
+body("pk_add_f32", [f"v_pk_add_f32 {d(64 + 2 * (i % 16))}, {d(32 + 2 * (i % 16))}, {d(64 + 2 * (i % 16))}" for i in range(64)], note="two f32 adds per lane")
+body("pk_mul_f32", [f"v_pk_mul_f32 {d(64 + 2 * (i % 16))}, {d(32 + 2 * (i % 16))}, v[2:3]" for i in range(64)], note="two f32 products per lane")
+body("add_f32_dpp", [f"v_add_f32_dpp v{64 + (i % 32)}, v{32 + (i % 32)}, v{64 + (i % 32)} row_ror:8 row_mask:0xf bank_mask:0xf" for i in range(64)], note="an add with its first operand from lane ^ 8")
 body("idle_nop", ["s_nop 15"] * 64, note="nothing but s_nop: the clocked-but-idle baseline")
 REPEAT = {k: 4 for k in BODIES}
 for k in ("bpermute", "fma_with_bpermute", "fma_with_lds_xchg", "fir_serial", "fir_x2", "fir_x4"): REPEAT[k] = 2
