@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How much of the oracle's results is owed to its choice of FFT (CPU only, test infrastructure).  The reference calls
 FFTW3 (f64, window energies) and libavcodec's RDFT (f32, frequency rating); neither can run here, the oracle restates
-them as a packed radix-2 (oracle/orc_fft.c).  This runs every case — the reference's recording tests/golden/song.flac
+them as a packed radix-2 (oracle/orc_fft.c; since round 6 the f32 one in libavcodec's own operation order,
+oracle/orc_fft_lavc.c, which tests/test_fft_independence.py singles out).  This runs every case — the reference's recording tests/golden/song.flac
 and the eight cases of tests/golden/synth_golden.json — under the three implementations of oracle/orc_fft_alt.c and
 reports, per case and per pair of implementations: how many f32 window energies differ and by how many ulp, whether
 any integer (beat, ...) or any of tempo / attack moves, and the absolute spread of `frequency`.
@@ -18,7 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-NAMES = {0: "packed radix-2 (orc_fft.c)", 1: "recursive radix-4, unpacked", 2: "defining sum, extended precision"}
+NAMES = {0: "the defaults: f64 packed radix-2 (orc_fft.c), f32 libavcodec's operation order since round 6 (orc_fft_lavc.c)", 1: "recursive radix-4, unpacked", 2: "defining sum, extended precision"}
 INTS = ("start", "end", "mean", "variance", "n_frames", "nb_frames", "n_windows", "beat", "calm_or_loud")
 
 
