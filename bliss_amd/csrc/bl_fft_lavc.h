@@ -64,6 +64,19 @@ BL_HD constexpr int lv_index(int L, int r) {
   return (lv_base(L) + (r < 8 ? lv_k_lo(r) : lv_k_hi(lv_lane_is_t16(L), r - 8))) & 255;
 }
 
+/* the same for the kernel, which cannot index a table by its lane: the T8 lanes as a bit mask, lv_base() as a byte per
+ * lane in two 64-bit words (lanes 0..7, 8..15) */
+BL_HD constexpr unsigned lv_t8_lane_mask() {
+  unsigned m = 0;
+  for (int L = 0; L < 16; ++L) m |= lv_lane_is_t16(L) ? 0u : 1u << L;
+  return m;
+}
+BL_HD constexpr unsigned long long lv_bases_packed(int half) {
+  unsigned long long v = 0;
+  for (int i = 0; i < 8; ++i) v |= (unsigned long long)lv_base(8 * half + i) << (8 * i);
+  return v;
+}
+
 /* per-lane twiddle slots of layout A (table lv_tw[slot * 16 + lane], filled by lv_fill_tables) */
 enum {
   LV_TW_P32 = 0,  /* pass(32):  k = lane & 7 */

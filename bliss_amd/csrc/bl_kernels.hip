@@ -549,14 +549,18 @@ __device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm
 
   /* this lane's place in the split-radix order (bl_fft_lavc.h): T8 lanes 1, 5, 7, 9, 13; base element lv_base(l),
    * from which the lanes with base >= 251 wrap for every register but the first */
-  const bool t16 = ((0x22A2u >> l) & 1u) == 0u;
-  const unsigned long long bases = l < 8 ? 0x06FE0A02FC040800ull : 0xFB0307FFFD050901ull; /* lv_base(), a byte per lane */
+  const bool t16 = ((lv_t8_lane_mask() >> l) & 1u) == 0u;
+  const unsigned long long bases = l < 8 ? lv_bases_packed(0) : lv_bases_packed(1);
   const int base0 = (int)((bases >> (8 * (l & 7))) & 0xFFu);
   const int basep = base0 >= 251 ? base0 - 256 : base0;
   const bool lo8 = l < 8;
-  /* gather order of the registers: lv_k_lo | lv_k_hi(true, .) */
-  constexpr int KG[16] = {0, 128, 64, 192, 32, 160, 224, 96, 16, 144, 80, 208, 240, 112, 48, 176};
-  static_assert(lv_gather_index(3, 1) == ((252 + 128) & 255) && lv_gather_index(12, 0) == 255 && lv_base(15) == 251, "lv tables");
+  /* gather order of the registers, the same for every lane: lv_k_lo | lv_k_hi(true, .) = what lane 0 (base 0) loads.
+   * Element of register r: (base0 + KG(r)) mod 256 = basep + KG(r) for r >= 1 (KG >= 16 > 5 >= -basep), base0 for r = 0 */
+#define KG(r) lv_gather_index(0, (r))
+  static_assert(lv_t8_lane_mask() == 0x22A2u && lv_bases_packed(0) == 0x06FE0A02FC040800ull &&
+                    lv_bases_packed(1) == 0xFB0307FFFD050901ull && KG(0) == 0 && KG(1) == 128 && KG(15) == 176 &&
+                    lv_gather_index(3, 1) == ((252 + KG(1)) & 255) && lv_gather_index(12, 0) == 255,
+                "bl_fft_lavc.h: lane tables");
 
   c2p *gx = xch + g * BL_FFT_XCH_ELEMS; /* the transpose buffer of this 16-lane group */
   float *stage = reinterpret_cast<float *>(xch + (g - gl) * BL_FFT_XCH_ELEMS); /* wave-private [8][BL_FREQ_SROW] */
@@ -575,7 +579,7 @@ __device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm
       const uint2 *qb = reinterpret_cast<const uint2 *>(p + (size_t)fb * 1024) + basep;
 #pragma unroll
       for (int r = 4 * part; r < 4 * part + 4; ++r) {
-        const int e = r == 0 ? base0 - basep : KG[r];
+        const int e = r == 0 ? base0 - basep : KG(r);
         pa[r] = qa[e]; pb[r] = qb[e];
       }
     } else {
@@ -583,7 +587,7 @@ __device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm
       const unsigned *qb = reinterpret_cast<const unsigned *>(p + (size_t)fb * 512) + basep;
 #pragma unroll
       for (int r = 4 * part; r < 4 * part + 4; ++r) {
-        const int e = r == 0 ? base0 - basep : KG[r];
+        const int e = r == 0 ? base0 - basep : KG(r);
         pa[r] = make_uint2(qa[e], 0u);
         pb[r] = make_uint2(qb[e], 0u);
       }
@@ -652,7 +656,7 @@ __device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm
         }
       }
       mono2(pa[r], pb[r], xr, xi);
-      const bl_f2 h = hann2[r == 0 ? base0 - basep : KG[r]]; /* hann[2 m], hann[2 m + 1] of this register's element m */
+      const bl_f2 h = hann2[r == 0 ? base0 - basep : KG(r)]; /* hann[2 m], hann[2 m + 1] of this register's element m */
       re[r] = xr * (bl_f2){h.x, h.x};
       im[r] = xi * (bl_f2){h.y, h.y};
     }
@@ -787,6 +791,8 @@ __device__ __forceinline__ void freq_frames_lavc(const int16_t *__restrict__ pcm
   if (SCAN)
     for (int i = tid; i < BL_HIST_BINS; i += 64 * WAVES) gh[i] = lh[i]; /* the workgroup owns the song: plain stores */
 }
+
+#undef KG
 
 /* one workgroup per song; the channel count is uniform per workgroup, so the branch costs one
  * scalar compare and each path keeps its compiled-in input side */
