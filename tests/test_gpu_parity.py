@@ -293,6 +293,39 @@ def test_mixed_length_corpus(gpu_lib, oracle):
         assert np.array_equal(got[k], host32[k]), k
 
 
+def test_quiet_sparse_and_clipped_material_bit_for_bit(gpu_lib, oracle):
+    """Material at the edges of the f32 transform's range, every feature held to the oracle's bits (check_song): a song
+    a few LSB loud (frames of tiny values: the power terms sit ~20 orders of magnitude below a loud song's, nowhere near
+    the subnormals), isolated impulses in digital silence (almost every frame all zero, single Hann-weighted samples
+    otherwise), full-scale square waves (the largest sums the transform can see), and a mono and a stereo song whose
+    length leaves every remainder of the 64-frame iteration."""
+    rate = 22050
+    rng = np.random.default_rng(66)
+    songs, chans, secs = [], [], []
+    base = oracle.synth(6601, rate, 2, rate * 2 * 14)
+    songs.append((base.astype(np.int32) // 900).astype(np.int16)); chans.append(2); secs.append(14)       # |s| <= 10
+    sparse = np.zeros(rate * 12, dtype=np.int16)
+    sparse[rng.integers(0, sparse.size, 400)] = rng.integers(-30000, 30000, 400, dtype=np.int64).astype(np.int16)
+    sparse[0], sparse[-1] = 5, -7
+    songs.append(sparse); chans.append(1); secs.append(12)
+    t = np.arange(rate * 2 * 9)
+    sq = np.where((t // 37) % 2 == 0, 32767, -32768).astype(np.int16)
+    sq[::1001] = 0   # a few quiet samples: the reference's histogram needs the central bins non-empty for a finite rating
+    songs.append(sq); chans.append(2); secs.append(9)
+    for k, ch in ((5, 1), (37, 2)):   # n_frames = 64 m + k
+        n = (64 * 9 + k) * 512 * ch + 77
+        songs.append(oracle.synth(6610 + k, rate, ch, n)); chans.append(ch); secs.append(max(1, n // (rate * ch)))
+    corpus = bliss_amd.DeviceCorpus([len(x) for x in songs], chans, secs)
+    for i, x in enumerate(songs):
+        corpus.upload(i, x)
+    corpus.analyze()
+    got = corpus.fetch()
+    for i, x in enumerate(songs):
+        ref = oracle.analyze(x, chans[i], secs[i])
+        assert int(ref["n_frames"]) == int(got[i]["n_frames"])
+        check_song(got[i], ref, f"edge[{i}]")
+
+
 def test_repeatability_and_order_independence(gpu_lib):
     """Run-to-run determinism and independence from the position in the batch (no float
     atomics, fixed-order partial sums)."""
